@@ -1,0 +1,59 @@
+"""Seeded synthetic inputs of the shapes the benchmarks name (NumPy, host side).
+
+SNAP .mtx files are not available offline, so tests and fixtures use graphs
+generated here.  Every generator returns zero-based (row, col) int32 arrays
+sorted by (col, row) with duplicates removed, which is the order SuiteSparse
+.mtx files list their entries in; the reference loader
+(serial_newblock_clock.cpp:108-112) keeps that order inside each CSR row, so
+rows come out with ascending column ids.
+"""
+import numpy as np
+
+
+def _finish(row, col, n):
+    key = np.unique(col.astype(np.int64) * n + row.astype(np.int64))
+    return (key % n).astype(np.int32), (key // n).astype(np.int32)
+
+
+def uniform(n, draws, seed):
+    """`draws` uniform (row, col) pairs on an n x n grid."""
+    rng = np.random.default_rng(seed)
+    row = rng.integers(0, n, draws)
+    col = rng.integers(0, n, draws)
+    return _finish(row, col, n)
+
+
+def rmat(scale, edge_factor, seed, diagonal=False, a=0.57, b=0.19, c=0.19):
+    """Graph500 R-MAT: edge_factor * 2^scale draws, one uniform number per level
+    choosing the quadrant: level l decides bit l of both ids (level 0 = least
+    significant bit); row bit set iff u >= a+b, column bit set iff a <= u < a+b or
+    u >= a+b+c.  No vertex scrambling.
+    `diagonal=True` adds (i, i) for every i (no empty rows)."""
+    n = 1 << scale
+    m = edge_factor << scale
+    rng = np.random.default_rng(seed)
+    row = np.zeros(m, np.int64)
+    col = np.zeros(m, np.int64)
+    for level in range(scale):
+        u = rng.random(m)
+        rbit = u >= a + b
+        cbit = ((u >= a) & (u < a + b)) | (u >= a + b + c)
+        row |= rbit.astype(np.int64) << level
+        col |= cbit.astype(np.int64) << level
+    if diagonal:
+        d = np.arange(n, dtype=np.int64)
+        row = np.concatenate([row, d])
+        col = np.concatenate([col, d])
+    return _finish(row, col, n)
+
+
+def write_mtx(path, n, row, col, pattern=True):
+    """MatrixMarket coordinate file, 1-based, in the given entry order."""
+    with open(path, "w") as f:
+        kind = "pattern" if pattern else "real"
+        f.write(f"%%MatrixMarket matrix coordinate {kind} general\n")
+        f.write(f"{n} {n} {len(row)}\n")
+        if pattern:
+            np.savetxt(f, np.stack([row + 1, col + 1], 1), fmt="%d %d")
+        else:
+            np.savetxt(f, np.stack([row + 1, col + 1, np.ones_like(row)], 1), fmt="%d %d %d")
