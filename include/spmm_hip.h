@@ -1,0 +1,95 @@
+/* libspmm_hip.so -- C ABI of the MI355X (gfx950) implementation of the XaryLee/spmm
+ * pre-processing pipeline and of the sparse product C = A*B it prepares for.
+ *
+ * The reference has no plugin or FFI interface: its seams are the in-process
+ * functions of PreProcessing/serial_newblock_clock.cpp and its headers.  Each
+ * entry point below replaces one of them and cites it.  A host program (the
+ * harness in spmm_amd/harness/serial.cpp, or the reference's own main()) calls
+ * these in place of the cited function.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SPMM_E_* code;
+ *     spmm_last_error() returns a message for the calling thread's last failure.
+ *   - pointers are HOST pointers unless the function name ends in _dev, in which
+ *     case every array pointer is a DEVICE pointer on the context's GPU and the
+ *     call is asynchronous on the context's stream (spmm_ctx_sync waits for it).
+ *   - all index arrays are int32 (the reference's `int`, csr.h:10-13), values are
+ *     fp64, row pointers of C are int64.
+ *   - outputs are caller-allocated at the sizes stated; nothing is returned that
+ *     the caller must free, except where spmm_free is named.
+ *   - one context per GPU; calls on one context must be serialised by the caller.
+ */
+#ifndef SPMM_HIP_H
+#define SPMM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmm_ctx spmm_ctx;
+
+enum {
+    SPMM_OK = 0,
+    SPMM_E_ARG = -1,        /* bad argument (null pointer, negative size, ncol > nrow where required) */
+    SPMM_E_HIP = -2,        /* a HIP runtime call failed */
+    SPMM_E_CAPACITY = -3,   /* a caller buffer is too small (e.g. block list) */
+    SPMM_E_UNSORTED = -4,   /* B's rows must have ascending column ids for the product */
+    SPMM_E_NODEVICE = -5    /* no usable GPU */
+};
+
+/* CSR matrix view: the layout of the reference's SpM (csr.h:8-20): shape = {nrow, ncol, nnz},
+ * indptr[nrow+1], indices[nnz], data[nnz]. */
+typedef struct {
+    int32_t nrow, ncol, nnz;
+    const int32_t* indptr;
+    const int32_t* indices;
+    const double* data;
+} spmm_csr;
+
+/* ---- context ---------------------------------------------------------- */
+int spmm_ctx_create(int device, spmm_ctx** out);
+int spmm_ctx_destroy(spmm_ctx* ctx);
+int spmm_ctx_sync(spmm_ctx* ctx);
+/* Use an existing HIP stream (hipStream_t passed as void*) for all later work on ctx. */
+int spmm_ctx_set_stream(spmm_ctx* ctx, void* hip_stream);
+const char* spmm_last_error(void);
+void spmm_free(void* p);
+/* Milliseconds of GPU time (hipEvent) spent by the kernels of the last host-pointer call on ctx. */
+double spmm_last_kernel_ms(spmm_ctx* ctx);
+
+/* ---- CSR build: replaces the in-memory part of csr_matrix(),
+ *      serial_newblock_clock.cpp:78-112 (row histogram, exclusive scan, scatter that keeps
+ *      input order inside a row; every value = 1.0).  row/col are zero-based, length nnz.
+ *      Outputs: indptr[nrow+1], indices[nnz], data[nnz]. */
+int spmm_csr_from_coo(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
+                      const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
+int spmm_csr_from_coo_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
+                          const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
+
+/* ---- sparse product C = A*B (not present in the reference; implied by wbsort.h:87-88,
+ *      where B = A).  B's rows must have ascending column ids (duplicates allowed).
+ *      symbolic: c_indptr[A.nrow+1] (int64), *nnz_c and *products (intermediate products,
+ *      sum over A entries (i,k) of len_B(k)) may be NULL.
+ *      numeric: rows [row_beg,row_end) of C written packed from position 0 of
+ *      c_indices/c_data, i.e. entry c_indptr[i]-c_indptr[row_beg]; column ids ascending. */
+int spmm_spgemm_symbolic(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* c_indptr,
+                         int64_t* nnz_c, int64_t* products);
+int spmm_spgemm_numeric(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const int64_t* c_indptr,
+                        int32_t row_beg, int32_t row_end, int32_t* c_indices, double* c_data);
+int spmm_spgemm_symbolic_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* c_indptr,
+                             int64_t* nnz_c, int64_t* products);
+int spmm_spgemm_numeric_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const int64_t* c_indptr,
+                            int32_t row_beg, int32_t row_end, int32_t* c_indices, double* c_data);
+/* Intermediate products per row (int64 prod[nrow], device) and their total; the quantity rows
+ * are binned and sharded by. */
+int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* prod, int64_t* total);
+/* Order-sensitive digest of a block of C held on the device: out[0] = sum over t of
+ * (indices[t]+1)*(2t+1) mod 2^64, out[1] = bit pattern of sum(data) accumulated in fp64 by
+ * atomics (exact for integer-valued data below 2^53).  out is a HOST pointer to 2 uint64. */
+int spmm_digest_dev(spmm_ctx* ctx, const int32_t* indices, const double* data, int64_t n, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

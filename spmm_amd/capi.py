@@ -1,0 +1,164 @@
+"""ctypes binding of libspmm_hip.so (include/spmm_hip.h).
+
+This is the host-side mirror used by the Python tests and by bench.py; the C++ harness
+(spmm_amd/harness/serial.cpp) links the same library directly.  There is no CPU fallback:
+if the library is missing, or no gfx950 GPU is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libspmm_hip.so")
+_LIB = None
+
+I32, I64, F64 = np.int32, np.int64, np.float64
+
+
+class SpmmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libspmm_hip error {code}: {msg}")
+        self.code = code
+
+
+class CsrView(C.Structure):
+    """spmm_csr: the reference's SpM layout (csr.h:8-20)."""
+    _fields_ = [("nrow", C.c_int32), ("ncol", C.c_int32), ("nnz", C.c_int32),
+                ("indptr", C.c_void_p), ("indices", C.c_void_p), ("data", C.c_void_p)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C spmm_amd/csrc` "
+                              "(or python -c 'import __graft_entry__ as g; g.build()')")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.spmm_last_error.restype = C.c_char_p
+        _LIB.spmm_last_kernel_ms.restype = C.c_double
+        _LIB.spmm_last_kernel_ms.argtypes = [C.c_void_p]
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise SpmmError(rc, lib().spmm_last_error().decode())
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.data_ptr())   # torch tensor
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Csr:
+    """Host CSR triple with the reference's dtypes."""
+
+    def __init__(self, nrow, ncol, indptr, indices, data):
+        self.nrow, self.ncol = int(nrow), int(ncol)
+        self.indptr, self.indices, self.data = _np(indptr, I32), _np(indices, I32), _np(data, F64)
+        self.nnz = int(self.indices.size)
+
+    def view(self):
+        return CsrView(self.nrow, self.ncol, self.nnz, self.indptr.ctypes.data, self.indices.ctypes.data,
+                       self.data.ctypes.data)
+
+
+def dev_view(nrow, ncol, nnz, indptr, indices, data):
+    """spmm_csr over device arrays (torch tensors or raw pointers)."""
+    return CsrView(int(nrow), int(ncol), int(nnz), _p(indptr).value, _p(indices).value if nnz else None,
+                   _p(data).value if nnz else None)
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(lib().spmm_ctx_create(C.c_int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().spmm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(lib().spmm_ctx_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        _chk(lib().spmm_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def last_kernel_ms(self):
+        return float(lib().spmm_last_kernel_ms(self._h))
+
+    # ---- CSR build (serial_newblock_clock.cpp:78-112) ---------------------
+    def csr_from_coo(self, nrow, ncol, row, col):
+        row, col = _np(row, I32), _np(col, I32)
+        nnz = row.size
+        indptr, indices, data = np.empty(nrow + 1, I32), np.empty(nnz, I32), np.empty(nnz, F64)
+        _chk(lib().spmm_csr_from_coo(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), _p(row), _p(col),
+                                     _p(indptr), _p(indices), _p(data)))
+        return Csr(nrow, ncol, indptr, indices, data)
+
+    def csr_from_coo_dev(self, nrow, ncol, nnz, row, col, indptr, indices, data):
+        _chk(lib().spmm_csr_from_coo_dev(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), _p(row), _p(col),
+                                         _p(indptr), _p(indices), _p(data)))
+
+    # ---- product -------------------------------------------------------------
+    def spgemm_symbolic(self, A, B=None):
+        B = A if B is None else B
+        va = A.view()
+        vb = va if B is A else B.view()
+        c_indptr = np.empty(A.nrow + 1, I64)
+        nnz_c, prods = C.c_int64(), C.c_int64()
+        _chk(lib().spmm_spgemm_symbolic(self._h, C.byref(va), C.byref(vb), _p(c_indptr), C.byref(nnz_c), C.byref(prods)))
+        return c_indptr, int(nnz_c.value), int(prods.value)
+
+    def spgemm_numeric(self, A, B, c_indptr, row_beg=0, row_end=None):
+        B = A if B is None else B
+        va = A.view()
+        vb = va if B is A else B.view()
+        row_end = A.nrow if row_end is None else row_end
+        c_indptr = _np(c_indptr, I64)
+        nz = int(c_indptr[row_end] - c_indptr[row_beg])
+        ci, cd = np.empty(nz, I32), np.empty(nz, F64)
+        _chk(lib().spmm_spgemm_numeric(self._h, C.byref(va), C.byref(vb), _p(c_indptr), C.c_int32(row_beg),
+                                       C.c_int32(row_end), _p(ci), _p(cd)))
+        return ci, cd
+
+    def spgemm(self, A, B=None):
+        c_indptr, nnz_c, prods = self.spgemm_symbolic(A, B)
+        ci, cd = self.spgemm_numeric(A, B, c_indptr)
+        return c_indptr, ci, cd
+
+    def spgemm_symbolic_dev(self, va, vb, c_indptr):
+        nnz_c, prods = C.c_int64(), C.c_int64()
+        _chk(lib().spmm_spgemm_symbolic_dev(self._h, C.byref(va), C.byref(vb), _p(c_indptr), C.byref(nnz_c), C.byref(prods)))
+        return int(nnz_c.value), int(prods.value)
+
+    def spgemm_numeric_dev(self, va, vb, c_indptr, row_beg, row_end, c_indices, c_data):
+        _chk(lib().spmm_spgemm_numeric_dev(self._h, C.byref(va), C.byref(vb), _p(c_indptr), C.c_int32(row_beg),
+                                           C.c_int32(row_end), _p(c_indices), _p(c_data)))
+
+    def row_products_dev(self, va, vb, prod):
+        total = C.c_int64()
+        _chk(lib().spmm_row_products_dev(self._h, C.byref(va), C.byref(vb), _p(prod), C.byref(total)))
+        return int(total.value)
+
+    def digest_dev(self, indices, data, n):
+        out = np.zeros(2, np.uint64)
+        _chk(lib().spmm_digest_dev(self._h, _p(indices), _p(data), C.c_int64(n), _p(out)))
+        return int(out[0]), float(out[1:2].view(np.float64)[0])

@@ -1,0 +1,135 @@
+// Shared host/device plumbing for libspmm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spmm_hip.h"
+
+// ---------------------------------------------------------------------------
+// errors
+void spmm_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            spmm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return SPMM_E_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+#define CHK(expr)                      \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != SPMM_OK) return rc_; \
+    } while (0)
+
+#define ARGCHK(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            spmm_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+            return SPMM_E_ARG;                                              \
+        }                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// context: one per GPU.  Device scratch lives in grow-only slots so that repeated
+// calls of the same size allocate nothing.
+enum ws_slot {
+    WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
+    WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
+    WS_STATE, WS_SORTKEY, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
+    WS_MISC7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
+    WS_NSLOTS
+};
+
+struct spmm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* slot[WS_NSLOTS] = {};
+    size_t slot_bytes[WS_NSLOTS] = {};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    int num_cu = 256;
+    void* pinned = nullptr;   // small pinned host buffer for scalar read-backs
+    size_t pinned_bytes = 0;
+};
+
+int ws_get(spmm_ctx* ctx, int slot, size_t bytes, void** out);
+template <typename T>
+inline int ws(spmm_ctx* ctx, int slot, size_t count, T** out) {
+    return ws_get(ctx, slot, count * sizeof(T), (void**)out);
+}
+
+// ---------------------------------------------------------------------------
+// device primitives shared by the kernels files (scan.hip / radix.hip)
+int dev_exclusive_scan_i32(spmm_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);          // out[n] = total too
+int dev_exclusive_scan_i32_i64(spmm_ctx* ctx, const int32_t* in, int64_t* out, int64_t n);      // out has n+1 entries
+int dev_exclusive_scan_i64(spmm_ctx* ctx, const int64_t* in, int64_t* out, int64_t n);          // out has n+1 entries
+// Stable LSD radix sort of (key, value) uint32 pairs on key bits [0, key_bits).  The sorted
+// pairs end in keys_out/vals_out (which must not alias the inputs); inputs are clobbered when
+// more than one pass is needed.  vals may be null on both sides (keys only).
+int dev_radix_sort_pairs(spmm_ctx* ctx, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+                         uint32_t* vals_out, int64_t n, int key_bits);
+
+static inline int bits_for(uint32_t max_value) {
+    int b = 1;
+    while (b < 32 && (max_value >> b)) b++;
+    return b;
+}
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------
+// wave / block helpers (wave = 64 lanes)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Exclusive scan across a block of THREADS threads.  tmp must hold THREADS/64 + 1 elements of T
+// in LDS.  Returns the exclusive prefix of v; *total receives the block sum.  Contains barriers:
+// every thread of the block must call it.
+template <int THREADS, typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* tmp, T* total) {
+    constexpr int NW = THREADS / 64;
+    T inc = wave_inclusive_scan(v);
+    int w = threadIdx.x >> 6;
+    __syncthreads();   // protects tmp against a previous use
+    if ((threadIdx.x & 63) == 63) tmp[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) { T x = tmp[i]; tmp[i] = run; run += x; }
+        tmp[NW] = run;
+    }
+    __syncthreads();
+    T base = tmp[w];
+    *total = tmp[NW];
+    return base + inc - v;
+}
+#endif

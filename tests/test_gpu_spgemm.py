@@ -1,0 +1,131 @@
+"""GPU: CSR build and the product C = A*B through the C ABI against the oracle and the
+golden fixtures.  Structure (row pointers, column ids) must be bit-exact; values are exact
+for the all-ones matrices the reference loader produces and within 1e-12 relative for
+general fp64."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from spmm_amd import capi, synth
+from tests.helpers import case_input, golden_json, golden_npz, hx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _ones_csr(n, row, col):
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    return capi.Csr(n, n, ip, ix, d)
+
+
+@pytest.mark.parametrize("name", ["tiny", "rmat12d", "rmat17d", "rmat18"])
+def test_csr_build_matches_golden(ctx, name):
+    J = golden_json("pre_" + name)
+    n, row, col = case_input(J)
+    M = ctx.csr_from_coo(n, n, row, col)
+    assert hx(M.indptr) == J["csr_indptr"] and hx(M.indices) == J["csr_indices"]
+    assert np.all(M.data == 1.0)
+
+
+def test_csr_build_edge_cases(ctx):
+    # empty matrix, ragged rows, duplicates, unsorted input order
+    M = ctx.csr_from_coo(5, 7, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert M.indptr.tolist() == [0] * 6 and M.nnz == 0
+    rng = np.random.default_rng(3)
+    row = rng.integers(0, 50, 5000).astype(np.int32)
+    col = rng.integers(0, 9000, 5000).astype(np.int32)
+    row[:100] = 7      # one long row
+    M = ctx.csr_from_coo(50, 9000, row, col)
+    ip, ix, d = orc.csr_from_coo(50, row, col)
+    assert np.array_equal(M.indptr, ip) and np.array_equal(M.indices, ix)
+    with pytest.raises(capi.SpmmError):
+        ctx.csr_from_coo(50, 10, row, col)     # column ids out of range
+
+
+@pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12d", "rmat14"])
+def test_product_matches_golden(ctx, name):
+    J = golden_json("spgemm_" + name)
+    n, row, col = case_input(J)
+    A = _ones_csr(n, row, col)
+    c_ip, nnz_c, prods = ctx.spgemm_symbolic(A)
+    assert prods == J["products"] and nnz_c == J["nnzC"]
+    assert hx(c_ip) == J["c_indptr"]
+    ci, cd = ctx.spgemm_numeric(A, None, c_ip)
+    assert hx(ci) == J["c_indices"]
+    assert hx(cd) == J["c_data"]
+    assert cd.sum() == J["products"]
+
+
+def test_product_full_arrays_and_row_ranges(ctx):
+    Z = golden_npz("spgemm_rmat10")
+    A = _ones_csr(1024, Z["row"], Z["col"])
+    c_ip, ci, cd = ctx.spgemm(A)
+    assert np.array_equal(c_ip, Z["c_indptr"]) and np.array_equal(ci, Z["c_indices"]) and np.array_equal(cd, Z["c_data"])
+    for r0, r1 in [(0, 1), (100, 400), (1000, 1024), (512, 512)]:
+        ci2, cd2 = ctx.spgemm_numeric(A, None, c_ip, r0, r1)
+        assert np.array_equal(ci2, ci[c_ip[r0]:c_ip[r1]]) and np.array_equal(cd2, cd[c_ip[r0]:c_ip[r1]])
+
+
+def test_product_rectangular_fp64(ctx):
+    Z = golden_npz("spgemm_rect")
+    A = capi.Csr(300, 200, Z["a_indptr"], Z["a_indices"], Z["a_data"])
+    B = capi.Csr(200, 500, Z["b_indptr"], Z["b_indices"], Z["b_data"])
+    c_ip, ci, cd = ctx.spgemm(A, B)
+    assert np.array_equal(c_ip, Z["c_indptr"]) and np.array_equal(ci, Z["c_indices"])
+    np.testing.assert_allclose(cd, Z["c_data"], rtol=1e-12, atol=1e-13)
+
+
+def test_product_heavy_rows_all_bins(ctx):
+    """A matrix whose rows fall in every bin, including rows with more distinct output columns
+    than one value sweep holds and duplicate entries in A (kept by the reference loader)."""
+    rng = np.random.default_rng(11)
+    n = 300000                      # two numeric windows of 262144 columns
+    rows, cols = [], []
+    # row 0: 40000 entries -> dense output over both windows; row 1: duplicates
+    rows.append(np.zeros(40000, np.int64)); cols.append(rng.integers(0, n, 40000))
+    rows.append(np.ones(600, np.int64)); cols.append(np.repeat(rng.integers(0, n, 300), 2))
+    m = 600000
+    rows.append(rng.integers(2, n, m)); cols.append(rng.integers(0, n, m))
+    # a hub column region so that some rows get many products
+    rows.append(rng.integers(2, 300, 9000)); cols.append(rng.integers(0, 50, 9000))
+    rows.append(rng.integers(0, 50, 100000)); cols.append(rng.integers(0, n, 100000))
+    row = np.concatenate(rows); col = np.concatenate(cols)
+    order = np.lexsort((row, col))           # (col,row) order, duplicates kept
+    row, col = row[order].astype(np.int32), col[order].astype(np.int32)
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    d = rng.integers(1, 4, d.size).astype(np.float64)
+    A = capi.Csr(n, n, ip, ix, d)
+    prod, total = orc.row_products(ip, ix, ip)
+    assert prod.max() > 100000 and (prod == 0).any() and ((prod > 0) & (prod <= 512)).any() and ((prod > 512) & (prod <= 4096)).any()
+    c_ip, nnz_c, prods = ctx.spgemm_symbolic(A)
+    o_ip = orc.spgemm_symbolic(n, n, ip, ix, ip, ix)
+    assert prods == total
+    assert np.array_equal(c_ip, o_ip)
+    assert np.diff(o_ip).max() > 8192 * 2      # more than two value sweeps in one row
+    ci, cd = ctx.spgemm_numeric(A, None, c_ip)
+    oi, od, _ = orc.spgemm_numeric(n, (ip, ix, d), (ip, ix, d), o_ip)
+    assert np.array_equal(ci, oi)
+    assert np.array_equal(cd, od)              # small integers: exact
+
+
+def test_product_rejects_unsorted_b(ctx):
+    ip = np.array([0, 2, 3], np.int32)
+    ix = np.array([1, 0, 1], np.int32)
+    A = capi.Csr(2, 2, ip, ix, np.ones(3))
+    with pytest.raises(capi.SpmmError) as e:
+        ctx.spgemm_symbolic(A)
+    assert e.value.code == -4
+
+
+def test_product_empty(ctx):
+    A = capi.Csr(4, 4, np.zeros(5, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    c_ip, nnz_c, prods = ctx.spgemm_symbolic(A)
+    assert c_ip.tolist() == [0] * 5 and nnz_c == 0 and prods == 0
+    ci, cd = ctx.spgemm_numeric(A, None, c_ip)
+    assert ci.size == 0
