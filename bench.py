@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""SpGEMM benchmark: C = A*A on a synthetic R-MAT graph, one process per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): Graph500 R-MAT scale 22, edge factor 16 (4.2M rows, ~65M nnz after
+dedup), every stored value 1.0 as the reference loader forces (serial_newblock_clock.cpp:84).
+A step = symbolic (nnz per C row) + numeric (sorted column ids + fp64 values) over the rank's
+rows of A, with A and B already resident in HBM.  C (about 6e10 entries at scale 22) does not
+fit any memory, so numeric runs over row blocks that reuse one output buffer.
+
+N > 1: rows of A are split across ranks by intermediate-product count; every rank builds the
+CSR of an even row slice and B is assembled on every GPU by an all-gather over RCCL (set-up,
+reported as b_allgather_ms).  The same matrix is used at every N (strong scaling).
+
+Rank 0 prints ONE JSON line.  value = 2 * products / step time, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from spmm_amd import capi  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+
+def rmat_torch(scale, edge_factor, seed, device):
+    """Graph500 R-MAT (a,b,c,d = .57,.19,.19,.05), level l decides bit l, no scrambling; dedup and
+    (col,row) order like a SuiteSparse file.  Philox stream of torch, seeded."""
+    a, b, c = 0.57, 0.19, 0.19
+    n, m = 1 << scale, edge_factor << scale
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    row = torch.zeros(m, dtype=torch.int64, device=device)
+    col = torch.zeros(m, dtype=torch.int64, device=device)
+    for level in range(scale):
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+        row |= (u >= a + b).to(torch.int64) << level
+        col |= (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64) << level
+        del u
+    key = torch.unique(col * n + row)
+    del row, col
+    return (key & (n - 1)).to(torch.int32), (key >> scale).to(torch.int32)
+
+
+def build_csr(ctx, n_rows, ncol, row, col):
+    nnz = row.numel()
+    dev = row.device
+    indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    data = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    ctx.csr_from_coo_dev(n_rows, ncol, nnz, row, col, indptr, indices, data)
+    return indptr, indices[:nnz], data[:nnz]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--cbuf-gib", type=float, default=48.0, help="output buffer (indices+values) per GPU")
+    ap.add_argument("--cpu-products", type=float, default=1.5e9, help="size of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = capi.Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---- set-up (untimed): graph, CSR, B on every GPU ------------------------
+    t0 = time.time()
+    n = 1 << args.scale
+    row, col = rmat_torch(args.scale, args.edge_factor, args.seed, dev)
+    nnz = int(row.numel())
+    b_allgather_ms = 0.0
+    if world == 1:
+        indptr, indices, data = build_csr(ctx, n, n, row, col)
+    else:
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        m = (row >= lo) & (row < hi)
+        ip_l, ix_l, _ = build_csr(ctx, hi - lo, n, (row[m] - lo).contiguous(), col[m].contiguous())
+        torch.cuda.synchronize()
+        cnt = torch.tensor([ix_l.numel()], dtype=torch.int64, device=dev)
+        cnts = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(cnts, cnt)
+        cnts_h = cnts.cpu().tolist()
+        mx = max(cnts_h)
+        pad = torch.zeros(mx, dtype=torch.int32, device=dev)
+        pad[:ix_l.numel()] = ix_l
+        rows_max = max((r + 1) * n // world - r * n // world for r in range(world))
+        lens = torch.zeros(rows_max, dtype=torch.int32, device=dev)
+        lens[:hi - lo] = ip_l[1:] - ip_l[:-1]
+        allix = torch.empty(world * mx, dtype=torch.int32, device=dev)
+        alllen = torch.empty(world * rows_max, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_gather_into_tensor(allix, pad)
+        dist.all_gather_into_tensor(alllen, lens)
+        e1.record()
+        torch.cuda.synchronize()
+        b_allgather_ms = e0.elapsed_time(e1)
+        indices = torch.cat([allix[r * mx: r * mx + cnts_h[r]] for r in range(world)])
+        lens_all = torch.cat([alllen[r * rows_max: r * rows_max + ((r + 1) * n // world - r * n // world)] for r in range(world)])
+        indptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        indptr[1:] = torch.cumsum(lens_all, 0).to(torch.int32)
+        data = torch.ones(nnz, dtype=torch.float64, device=dev)
+        del allix, alllen, pad, m
+        assert int(indptr[-1]) == nnz == indices.numel()
+    del row, col
+    torch.cuda.synchronize()
+
+    vB = capi.dev_view(n, n, nnz, indptr, indices, data)
+    prod = torch.empty(n, dtype=torch.int64, device=dev)
+    P_total = ctx.row_products_dev(vB, vB, prod)
+    # rows of A per rank: equal shares of the intermediate products
+    cum = torch.cumsum(prod, 0)
+    bounds = [0]
+    for r in range(1, world):
+        bounds.append(int(torch.searchsorted(cum, torch.tensor([P_total * r // world], device=dev, dtype=torch.int64))[0]))
+    bounds.append(n)
+    r_lo, r_hi = bounds[rank], bounds[rank + 1]
+    rows_l = r_hi - r_lo
+    P_local = int(prod[r_lo:r_hi].sum())
+    vA = capi.dev_view(rows_l, n, nnz, indptr[r_lo:], indices, data)
+
+    c_ip = torch.empty(rows_l + 1, dtype=torch.int64, device=dev)
+    cap = int(args.cbuf_gib * (1 << 30) / 12)
+    c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
+    c_val = torch.empty(cap, dtype=torch.float64, device=dev)
+    setup_s = time.time() - t0
+
+    state = {}
+
+    def plan_blocks(c_ip_h):
+        blocks, r0 = [], 0
+        while r0 < rows_l:
+            r1 = int(np.searchsorted(c_ip_h, c_ip_h[r0] + cap, side="right")) - 1
+            if r1 <= r0:
+                raise RuntimeError(f"row {r_lo + r0} of C has more entries than the output buffer holds")
+            r1 = min(r1, rows_l)
+            blocks.append((r0, r1))
+            r0 = r1
+        return blocks
+
+    def step(verify=False):
+        nnz_c, _ = ctx.spgemm_symbolic_dev(vA, vB, c_ip)
+        c_ip_h = c_ip.cpu().numpy()
+        blocks = plan_blocks(c_ip_h)
+        state.update(nnz_c=nnz_c, blocks=len(blocks), c_ip_h=c_ip_h)
+        vsum, hsum = 0.0, 0
+        for (b0, b1) in blocks:
+            ctx.spgemm_numeric_dev(vA, vB, c_ip, b0, b1, c_ix, c_val)
+            if verify:
+                h, s = ctx.digest_dev(c_ix, c_val, int(c_ip_h[b1] - c_ip_h[b0]))
+                vsum += s
+                hsum = (hsum + h) & ((1 << 64) - 1)
+        return vsum, hsum
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (first one verifies: all-ones inputs => sum of C's values == products) -------
+    for w in range(max(args.warmup, 1)):
+        vsum, hsum = step(verify=(w == 0))
+        if w == 0:
+            assert vsum == float(P_local), f"rank {rank}: sum(C) = {vsum} but the rows hold {P_local} products"
+    nnz_c_local = state["nnz_c"]
+
+    # ---- timed region --------------------------------------------------------
+    ctx.profile(True)
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t1
+    ph = {name: ctx.phase_ms(pid) for name, pid in
+          [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
+           ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN)]}
+    ctx.profile(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(nnz_c_local)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(tmax[0])
+    nnz_c_total = int(tot[0])
+    ms_per_step = dt / args.steps * 1e3
+    gflops = 2.0 * P_total / (dt / args.steps) / 1e9
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: numeric over the window rows (rank 0's share) -------
+    esc_s, esc_l = capi.bin_limits()
+    pl = prod[r_lo:r_hi]
+    wmask = pl > esc_l
+    lens_l = (indptr[r_lo + 1:r_hi + 1] - indptr[r_lo:r_hi]).to(torch.int64)
+    rowc = c_ip[1:] - c_ip[:-1]
+    P_w, nnzA_w, rows_w, nnzC_w = int(pl[wmask].sum()), int(lens_l[wmask].sum()), int(wmask.sum()), int(rowc[wmask].sum())
+    bytes_w = 12 * P_w + 20 * nnzA_w + 12 * (rows_w + 1) + 12 * nnzC_w
+    t_w_ms = ph["window_num"][0] / args.steps
+    achieved = bytes_w / (t_w_ms * 1e-3) / 1e9 if t_w_ms > 0 else 0.0
+    roofline = dict(bound="hbm", kernel="k_window<numeric>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_step=bytes_w, kernel_ms_per_step=round(t_w_ms, 3),
+                    launches_per_step=ph["window_num"][1] // max(args.steps, 1),
+                    numeric_gflops=round(2.0 * P_w / (t_w_ms * 1e-3) / 1e9, 1) if t_w_ms > 0 else None)
+
+    # ---- CPU baseline: the oracle's serial Gustavson on the first rows of the same matrix -----
+    cpu = None
+    if not args.no_cpu and world == 1:
+        from oracle import oracle as orc
+        target = args.cpu_products
+        cum_h = cum[:min(n, 1 << 22)].cpu().numpy()
+        R = int(np.searchsorted(cum_h, target)) + 1
+        R = max(1, min(R, rows_l if world > 1 else n))
+        ip_h, ix_h = indptr.cpu().numpy(), indices.cpu().numpy()
+        d_h = np.ones(nnz, np.float64)
+        tc = time.perf_counter()
+        o_ip = orc.spgemm_symbolic(R, n, ip_h[:R + 1], ix_h, ip_h, ix_h)
+        oi, od, p_s = orc.spgemm_numeric(n, (ip_h[:R + 1], ix_h, d_h), (ip_h, ix_h, d_h), o_ip)
+        tcpu = time.perf_counter() - tc
+        cpu = dict(value=round(2.0 * p_s / tcpu / 1e9, 4), unit="GFLOP/s", cores=1, kind="port",
+                   sample=f"rows 0..{R - 1} of the same matrix ({p_s} products, symbolic+numeric, {tcpu:.1f} s)",
+                   host_cpus=os.cpu_count())
+        # the same rows from the GPU must match the oracle exactly
+        if r_lo == 0 and R <= rows_l and int(o_ip[-1]) <= cap:
+            assert np.array_equal(state["c_ip_h"][:R + 1], o_ip), "GPU row pointers differ from the oracle"
+            ctx.spgemm_numeric_dev(vA, vB, c_ip, 0, R, c_ix, c_val)
+            torch.cuda.synchronize()
+            k = int(o_ip[-1])
+            assert np.array_equal(c_ix[:k].cpu().numpy(), oi), "GPU column ids differ from the oracle"
+            assert np.array_equal(c_val[:k].cpu().numpy(), od), "GPU values differ from the oracle"
+            cpu["gpu_rows_match_oracle"] = True
+
+    out = dict(metric="spgemm_gflops", value=round(gflops, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",
+               vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=f"R-MAT scale {args.scale} edge factor {args.edge_factor} seed {args.seed}, C=A*A, all values 1.0",
+                           rows=n, nnz=nnz, products=P_total, nnz_c=nnz_c_total, partition="rows of A by product count",
+                           step="symbolic+numeric", c_row_blocks_per_step=state["blocks"], rank0_rows=rows_l,
+                           b_allgather_ms=round(b_allgather_ms, 3), setup_s=round(setup_s, 1)),
+               phases_ms_per_step={k: round(v[0] / args.steps, 3) for k, v in ph.items()},
+               roofline=roofline, cpu_baseline=cpu)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,28 @@ void spmm_free(void* p);
 /* Milliseconds of GPU time (hipEvent) spent by the kernels of the last host-pointer call on ctx. */
 double spmm_last_kernel_ms(spmm_ctx* ctx);
 
+/* Per-phase GPU time.  spmm_ctx_profile(ctx,1) starts a session (and clears the previous one):
+ * from then on every kernel group named by an SPMM_PH_* id is bracketed by hipEvents on the
+ * context's stream.  spmm_ctx_phase_ms waits for the stream and returns the summed duration and
+ * the number of bracketed launches of one phase since the session started.  Has no counterpart in
+ * the reference, whose timers are std::chrono brackets (serial_newblock_clock.cpp:24-35). */
+enum {
+    SPMM_PH_BINS = 0,        /* row products + binning + ordering of the heavy rows */
+    SPMM_PH_WINDOW_SYM = 1,  /* symbolic, window rows */
+    SPMM_PH_ESC_SYM = 2,     /* symbolic, expand/sort/compress rows */
+    SPMM_PH_WINDOW_NUM = 3,  /* numeric, window rows (the dominant kernel on R-MAT inputs) */
+    SPMM_PH_ESC_NUM = 4,     /* numeric, expand/sort/compress rows */
+    SPMM_PH_SCAN = 5,        /* row-count scan -> C row pointers */
+    SPMM_PH_CSR_BUILD = 6,
+    SPMM_PH_COUNT = 32
+};
+int spmm_ctx_profile(spmm_ctx* ctx, int enable);
+int spmm_ctx_phase_ms(spmm_ctx* ctx, int phase, double* total_ms, int* launches);
+/* Row-bin limits of the product: rows with at most *esc_small / *esc_large intermediate products
+ * are handled by the 64-lane / 256-thread expand-sort-compress kernels, heavier rows by the
+ * window kernel. */
+void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
+
 /* ---- CSR build: replaces the in-memory part of csr_matrix(),
  *      serial_newblock_clock.cpp:78-112 (row histogram, exclusive scan, scatter that keeps
  *      input order inside a row; every value = 1.0).  row/col are zero-based, length nnz.

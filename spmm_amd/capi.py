@@ -16,6 +16,15 @@ _LIB = None
 I32, I64, F64 = np.int32, np.int64, np.float64
 
 
+PH_BINS, PH_WINDOW_SYM, PH_ESC_SYM, PH_WINDOW_NUM, PH_ESC_NUM, PH_SCAN, PH_CSR_BUILD = range(7)
+
+
+def bin_limits():
+    a, b = C.c_int32(), C.c_int32()
+    lib().spmm_spgemm_bin_limits(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
 class SpmmError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libspmm_hip error {code}: {msg}")
@@ -100,6 +109,14 @@ class Context:
 
     def set_stream(self, stream_ptr):
         _chk(lib().spmm_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def profile(self, enable=True):
+        _chk(lib().spmm_ctx_profile(self._h, C.c_int(1 if enable else 0)))
+
+    def phase_ms(self, phase):
+        ms, n = C.c_double(), C.c_int()
+        _chk(lib().spmm_ctx_phase_ms(self._h, C.c_int(phase), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def last_kernel_ms(self):
         return float(lib().spmm_last_kernel_ms(self._h))

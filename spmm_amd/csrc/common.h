@@ -48,7 +48,12 @@ enum ws_slot {
     WS_NSLOTS
 };
 
+struct phase_rec { int phase; hipEvent_t e0, e1; };
+
 struct spmm_ctx {
+    bool profile = false;
+    std::vector<phase_rec> recs;       // recorded this profiling session
+    std::vector<phase_rec> free_recs;  // event pairs ready for reuse
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -62,6 +67,10 @@ struct spmm_ctx {
 };
 
 int ws_get(spmm_ctx* ctx, int slot, size_t bytes, void** out);
+
+// Per-phase GPU timing (hipEvents on the context's stream), active only while profiling is on.
+int phase_begin(spmm_ctx* ctx, int phase);   // returns a record index or -1
+void phase_end(spmm_ctx* ctx, int rec);
 template <typename T>
 inline int ws(spmm_ctx* ctx, int slot, size_t count, T** out) {
     return ws_get(ctx, slot, count * sizeof(T), (void**)out);

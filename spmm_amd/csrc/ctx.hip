@@ -57,6 +57,8 @@ extern "C" int spmm_ctx_destroy(spmm_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int i = 0; i < WS_NSLOTS; i++)
         if (c->slot[i]) hipFree(c->slot[i]);
+    for (auto& r : c->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : c->free_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     if (c->pinned) hipHostFree(c->pinned);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -98,5 +100,52 @@ int ws_get(spmm_ctx* c, int slot, size_t bytes, void** out) {
         c->slot_bytes[slot] = want;
     }
     *out = c->slot[slot];
+    return SPMM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-phase timing
+int phase_begin(spmm_ctx* c, int phase) {
+    if (!c->profile) return -1;
+    phase_rec r;
+    if (!c->free_recs.empty()) {
+        r = c->free_recs.back();
+        c->free_recs.pop_back();
+    } else {
+        if (hipEventCreate(&r.e0) != hipSuccess) return -1;
+        if (hipEventCreate(&r.e1) != hipSuccess) { hipEventDestroy(r.e0); return -1; }
+    }
+    r.phase = phase;
+    hipEventRecord(r.e0, c->stream);
+    c->recs.push_back(r);
+    return (int)c->recs.size() - 1;
+}
+
+void phase_end(spmm_ctx* c, int rec) {
+    if (rec < 0 || rec >= (int)c->recs.size()) return;
+    hipEventRecord(c->recs[rec].e1, c->stream);
+}
+
+extern "C" int spmm_ctx_profile(spmm_ctx* c, int enable) {
+    ARGCHK(c != nullptr);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& r : c->recs) c->free_recs.push_back(r);
+    c->recs.clear();
+    c->profile = enable != 0;
+    return SPMM_OK;
+}
+
+extern "C" int spmm_ctx_phase_ms(spmm_ctx* c, int phase, double* total_ms, int* launches) {
+    ARGCHK(c != nullptr && total_ms != nullptr);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double t = 0.0;
+    int n = 0;
+    for (auto& r : c->recs) {
+        if (r.phase != phase) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { t += ms; n++; }
+    }
+    *total_ms = t;
+    if (launches) *launches = n;
     return SPMM_OK;
 }

@@ -398,6 +398,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
                Bins* out) {
     const int32_t nrow = A->nrow;
     long long* counters;
+    int ph = phase_begin(ctx, SPMM_PH_BINS);
     CHK(ws(ctx, WS_COUNTERS, CNT_N, &counters));
     CHK(ws(ctx, WS_PROD, (size_t)nrow + 1, &out->prod));
     CHK(ws(ctx, WS_LIST_ESC_S, (size_t)nrow + 1, &out->list_s));
@@ -443,6 +444,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->products = h[CNT_PRODUCTS];
     if (out->n_w > 0)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
+    phase_end(ctx, ph);
     return SPMM_OK;
 }
 
@@ -454,21 +456,30 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         CHK(ws(ctx, WS_STATE, (size_t)A->nnz + 1, &state));
         size_t lds = win_lds_bytes(NUMERIC);
         HIPCHK(hipFuncSetAttribute((const void*)k_window<NUMERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
         hipLaunchKernelGGL(k_window<NUMERIC>, dim3((unsigned)bins.n_w), dim3(WIN_THREADS), lds, ctx->stream, bins.list_w,
                            B->ncol, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, bins.prod, state,
                            rowcnt, c_ip, row_beg, c_ix, c_val);
+        phase_end(ctx, ph);
     }
+    int ph_esc = phase_begin(ctx, NUMERIC ? SPMM_PH_ESC_NUM : SPMM_PH_ESC_SYM);
     if (bins.n_l > 0)
         hipLaunchKernelGGL((k_esc<256, ESC_L_CAP, NUMERIC>), dim3((unsigned)bins.n_l), dim3(256), 0, ctx->stream, bins.list_l,
                            A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
     if (bins.n_s > 0)
         hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)bins.n_s), dim3(64), 0, ctx->stream, bins.list_s,
                            A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
+    phase_end(ctx, ph_esc);
     HIPCHK(hipGetLastError());
     return SPMM_OK;
 }
 
 }  // namespace
+
+extern "C" void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large) {
+    if (esc_small) *esc_small = ESC_S_CAP;
+    if (esc_large) *esc_large = ESC_L_CAP;
+}
 
 extern "C" int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* prod, int64_t* total) {
     ARGCHK(ctx != nullptr);
@@ -497,7 +508,9 @@ extern "C" int spmm_spgemm_symbolic_dev(spmm_ctx* ctx, const spmm_csr* A, const 
     CHK(ws(ctx, WS_ROWCNT, (size_t)A->nrow + 1, &rowcnt));
     HIPCHK(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * ((size_t)A->nrow + 1), ctx->stream));
     CHK(launch_rows<false>(ctx, A, B, bins, rowcnt, nullptr, 0, nullptr, nullptr));
+    int ph = phase_begin(ctx, SPMM_PH_SCAN);
     CHK(dev_exclusive_scan_i32_i64(ctx, rowcnt, c_indptr, A->nrow));
+    phase_end(ctx, ph);
     if (products) *products = bins.products;
     if (nnz_c) {
         int64_t* h = (int64_t*)ctx->pinned;
