@@ -43,15 +43,24 @@ void spmm_set_error(const char* fmt, ...);
 enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
     WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
-    WS_STATE, WS_SORTKEY, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
+    WS_WINPTR, WS_SORTKEY, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     WS_NSLOTS
 };
 
 struct phase_rec { int phase; hipEvent_t e0, e1; };
 
+// What the last product call computed for (A, B): row products and B's window-pointer table.
+struct plan_cache {
+    bool valid = false;
+    const void *a_ip = nullptr, *a_ix = nullptr, *b_ip = nullptr, *b_ix = nullptr;
+    int a_nrow = 0, b_nrow = 0, b_ncol = 0, b_nnz = 0;
+};
+
 struct spmm_ctx {
     bool profile = false;
+    plan_cache plan;
+    int win_cfg = 0;   // window-kernel geometry: 0 = 1024 threads, 1 = 512 threads (2 workgroups per CU)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse
     int device = 0;

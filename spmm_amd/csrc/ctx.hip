@@ -1,5 +1,6 @@
 // Context, error reporting and scratch management of libspmm_hip.so.
 #include "common.h"
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -38,6 +39,7 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
         return SPMM_E_HIP;
     }
     c->own_stream = true;
+    if (const char* e = getenv("SPMM_WIN_CFG")) c->win_cfg = atoi(e);
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
     c->pinned_bytes = 4096;

@@ -24,10 +24,8 @@ namespace {
 
 constexpr int ESC_S_CAP = 512;
 constexpr int ESC_L_CAP = 4096;
-constexpr int WIN_THREADS = 1024;
-constexpr int WIN_VALS = 8192;          // fp64 accumulators per value sweep (64 KB)
-constexpr int WIN_WORDS_NUM = 8192;     // numeric window: 8192 x 32 = 262144 columns
-constexpr int WIN_WORDS_SYM = 32768;    // symbolic window: 1048576 columns (bitmap only)
+constexpr int WIN_SHIFT_MIN = 15;       // base column window of the table: 2^15 .. 2^17 columns
+constexpr int WIN_SHIFT_MAX = 17;
 constexpr int KEY_PAD = 0x7fffffff;
 
 enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_N = 8 };
@@ -54,15 +52,16 @@ __global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrow
     }
 }
 
-__global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, const int32_t* __restrict__ ip,
+__global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol, const int32_t* __restrict__ ip,
                                                       const int32_t* __restrict__ ix, long long* __restrict__ counters) {
     int64_t nnz = ip[nrow];
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // position p is a violation when ix[p] < ix[p-1] and p is not the first entry of its row.
-    // Row starts are found by marking: a decreasing pair is legal only across a row boundary,
-    // which a binary search over indptr decides for the few candidates.
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; p < nnz; p += stride) {
-        if (ix[p] < ix[p - 1]) {
+    // position p is a violation when ix[p] < ix[p-1] and p is not the first entry of its row: a
+    // decreasing pair is legal only across a row boundary, which a binary search over indptr
+    // decides for the few candidates.  Column ids must also lie in [0, ncol).
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+        if ((uint32_t)ix[p] >= (uint32_t)ncol) counters[CNT_BAD] = 1;
+        if (p > 0 && ix[p] < ix[p - 1]) {
             int lo = 0, hi = nrow;   // find row r with ip[r] <= p < ip[r+1]
             while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ip[mid] <= p) lo = mid; else hi = mid - 1; }
             if (ip[lo] != p) counters[CNT_UNSORTED] = 1;
@@ -170,85 +169,154 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
 }
 
 // ---------------------------------------------------------------------------
-// Window rows.
-struct WinShared {
-    int32_t tmp[WIN_THREADS / 64 + 1];
-    int32_t cstar;
-};
+// Window-pointer table of B: T[k][w] = first position of row k whose column id is >= w << shift,
+// for w = 0..nbase (T[k][nbase] = end of row k).  With it the part of B row k that falls into a
+// column window is known without touching B's column ids.  One wave per row.
+__global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __restrict__ b_ip,
+                                                const int32_t* __restrict__ b_ix, int shift, int nbase,
+                                                int32_t* __restrict__ winptr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t k = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nrowB; k += nw) {
+        const int r0 = b_ip[k], r1 = b_ip[k + 1];
+        int32_t* T = winptr + k * (int64_t)(nbase + 1);
+        if (r0 == r1) {
+            for (int w = lane; w <= nbase; w += 64) T[w] = r0;
+            continue;
+        }
+        for (int p = r0 + lane; p < r1; p += 64) {
+            int wcur = b_ix[p] >> shift;
+            int wprev = p == r0 ? -1 : (b_ix[p - 1] >> shift);
+            for (int w = wprev + 1; w <= wcur; w++) T[w] = p;
+            if (p == r1 - 1)
+                for (int w = wcur + 1; w <= nbase; w++) T[w] = r1;
+        }
+    }
+}
 
-template <bool NUMERIC>
-__global__ void __launch_bounds__(WIN_THREADS) k_window(const int32_t* __restrict__ list, int32_t ncolB,
-                                                        const int32_t* __restrict__ a_ip, const int32_t* __restrict__ a_ix,
-                                                        const double* __restrict__ a_val, const int32_t* __restrict__ b_ip,
-                                                        const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
-                                                        const int64_t* __restrict__ prod, int4* __restrict__ state,
-                                                        int32_t* __restrict__ rowcnt, const int64_t* __restrict__ c_ip,
-                                                        int32_t row_beg, int32_t* __restrict__ c_ix,
-                                                        double* __restrict__ c_val) {
-    constexpr int WORDS = NUMERIC ? WIN_WORDS_NUM : WIN_WORDS_SYM;
-    constexpr int WCOLS = WORDS * 32;
-    constexpr int WPT = WORDS / WIN_THREADS;   // bitmap words owned by a thread
+// ---------------------------------------------------------------------------
+// Window rows: one workgroup per row of A.
+//
+// LDS: bitmap of the current column window (WORDS x 32 columns), for numeric also the rank
+// prefix per bitmap word and VALS fp64 accumulators, and a directory of up to THREADS A entries:
+// dir_off[e] = number of products of the entries before e in this window, dir_start[e] = where
+// entry e's part of its B row starts.  A sweep walks the flattened product index space: each
+// wave takes a contiguous range, 64 products per step, finds the entry of a product by a
+// galloping search in dir_off (products are visited in increasing order, so the search starts
+// from the previous hit), and issues U independent loads before it touches the accumulators.
+template <int THREADS>
+__device__ __forceinline__ int win_build_dir(int c0, int lenA, int a0, const int32_t* __restrict__ a_ix,
+                                             const int32_t* __restrict__ winptr, int64_t tstride, int w0, int w1,
+                                             int32_t* dir_off, int32_t* dir_start, int32_t* tmp) {
+    __syncthreads();   // earlier readers of the directory are done
+    const int e = c0 + (int)threadIdx.x;
+    int s = 0, len = 0;
+    if (e < lenA) {
+        const int32_t* T = winptr + (int64_t)a_ix[a0 + e] * tstride;
+        s = T[w0];
+        len = T[w1] - s;
+    }
+    int tot;
+    int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot);
+    dir_off[threadIdx.x] = off;
+    dir_start[threadIdx.x] = s;
+    if (threadIdx.x == 0) dir_off[THREADS] = tot;
+    __syncthreads();
+    return tot;
+}
+
+// largest e' >= e with dir_off[e'] <= p; requires dir_off[e] <= p < dir_off[nent]
+__device__ __forceinline__ int win_advance(int e, int p, const int32_t* dir_off, int nent) {
+    int lo = e, step = 1;
+    while (lo + step < nent && dir_off[lo + step] <= p) { lo += step; step <<= 1; }
+    int hi = lo + step < nent ? lo + step : nent;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (dir_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int WIN_U = 4;   // independent loads in flight per lane
+
+template <int THREADS, int WORDS, int VALS, bool NUMERIC>
+__global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                 const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
+                                                 const int32_t* __restrict__ winptr, int nbase, int shift, int32_t ncolB,
+                                                 int32_t* __restrict__ rowcnt, const int64_t* __restrict__ c_ip,
+                                                 int32_t row_beg, int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
+    static_assert(!NUMERIC || VALS <= WORDS, "column staging reuses the rank-prefix array");
+    constexpr int WPT = WORDS / THREADS;
+    constexpr int NW = THREADS / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* bits = (uint32_t*)smem;
-    uint32_t* pre = bits + WORDS;                                   // NUMERIC only
-    double* vals = (double*)(smem + (size_t)WORDS * 8);             // NUMERIC only
-    WinShared* sh = (WinShared*)(smem + (NUMERIC ? (size_t)WORDS * 8 + (size_t)WIN_VALS * 8 : (size_t)WORDS * 4));
+    uint32_t* pre = bits + WORDS;                                                       // NUMERIC
+    double* vals = (double*)(smem + (size_t)WORDS * 8);                                 // NUMERIC
+    int32_t* dir_off = (int32_t*)(smem + (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4));
+    int32_t* dir_start = dir_off + THREADS + 2;
+    int32_t* tmp = dir_start + THREADS;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = list[blockIdx.x];
     const int a0 = a_ip[row];
     const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    const bool single_chunk = lenA <= THREADS;
 
-    // lanes per A entry: about one B segment's worth of elements, a power of two <= 64
-    int G = 1;
-    {
-        long long nwin = ((long long)ncolB + WCOLS - 1) / WCOLS;
-        long long est = prod[row] / (lenA > 0 ? lenA : 1) / (nwin > 0 ? nwin : 1);
-        while (G < 64 && G < est) G <<= 1;
-    }
-    const int ngroups = WIN_THREADS / G;
-    const int g = tid / G, t = tid & (G - 1);
-    const int gshift = (tid & 63) & ~(G - 1);
-    const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-
-    for (int e = tid; e < lenA; e += WIN_THREADS) {
-        int k = a_ix[a0 + e];
-        int b0 = b_ip[k], b1 = b_ip[k + 1];
-        state[a0 + e] = make_int4(b0, b1, b0 < b1 ? b_ix[b0] : KEY_PAD, 0);
-    }
-    for (int i = tid; i < WORDS; i += WIN_THREADS) bits[i] = 0u;
-    if (NUMERIC)
-        for (int i = tid; i < WIN_VALS; i += WIN_THREADS) vals[i] = 0.0;
-    __syncthreads();
-
+    // base windows per LDS window
+    int m = (WORDS * 32) >> shift;
     int64_t out = 0;
-    if (NUMERIC) out = c_ip[row] - c_ip[row_beg];
-    int mycount = 0;   // symbolic: set bits seen in this thread's words
+    if (NUMERIC) {
+        out = c_ip[row] - c_ip[row_beg];
+        const long long nnz_row = c_ip[row + 1] - c_ip[row];
+        const long long cols_t = nnz_row > 0 ? (long long)(VALS - VALS / 4) * ncolB / nnz_row : (long long)WORDS * 32;
+        while (m > 1 && ((long long)m << shift) > cols_t) m >>= 1;
+    }
 
-    for (long long wb = 0; wb < ncolB; wb += WCOLS) {
-        const int wbase = (int)wb;
-        const int wend = (int)(wb + WCOLS < (long long)ncolB ? wb + WCOLS : (long long)ncolB);
-        // ---- bit sweep -------------------------------------------------------
-        int dirty = 0;
-        for (int e = g; e < lenA; e += ngroups) {
-            int4 st = state[a0 + e];
-            if (st.z >= wend) continue;
-            int cur = st.x;
-            const int end = st.y;
-            dirty = 1;
-            while (true) {
-                int idx = cur + t;
-                bool ok = idx < end;
-                int c = ok ? b_ix[idx] : KEY_PAD;
-                ok = ok && c < wend;
-                if (ok) atomicOr(&bits[(c - wbase) >> 5], 1u << ((c - wbase) & 31));
-                int cnt = __popcll((__ballot(ok) >> gshift) & gmask);
-                cur += cnt;
-                if (cnt < G) break;
+    for (int i = tid; i < WORDS; i += THREADS) bits[i] = 0u;
+    if (NUMERIC)
+        for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
+    int mycount = 0;
+
+    for (int w0 = 0; w0 < nbase; w0 += m) {
+        const int w1 = w0 + m < nbase ? w0 + m : nbase;
+        const int wbase = w0 << shift;
+        // ---- bit sweep: one bit per touched column ---------------------------
+        long long Tw = 0;
+        int Tc = 0;
+        for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+            Tc = win_build_dir<THREADS>(c0, lenA, a0, a_ix, winptr, tstride, w0, w1, dir_off, dir_start, tmp);
+            Tw += Tc;
+            if (Tc == 0) continue;
+            const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+            const int p_lo = wv * per;
+            const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+            int e = 0;
+            for (int pb = p_lo; pb < p_hi; pb += 64 * WIN_U) {
+                int pos[WIN_U];
+                bool ok[WIN_U];
+#pragma unroll
+                for (int j = 0; j < WIN_U; j++) {
+                    int p = pb + j * 64 + lane;
+                    ok[j] = p < p_hi;
+                    pos[j] = 0;
+                    if (ok[j]) {
+                        e = win_advance(e, p, dir_off, THREADS);
+                        pos[j] = dir_start[e] + (p - dir_off[e]);
+                    }
+                }
+                int c[WIN_U];
+#pragma unroll
+                for (int j = 0; j < WIN_U; j++) c[j] = ok[j] ? b_ix[pos[j]] : 0;
+#pragma unroll
+                for (int j = 0; j < WIN_U; j++)
+                    if (ok[j]) atomicOr(&bits[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
             }
-            if (!NUMERIC && t == 0) state[a0 + e] = make_int4(cur, end, cur < end ? b_ix[cur] : KEY_PAD, 0);
         }
-        if (!__syncthreads_or(dirty)) continue;
+        if (Tw == 0) continue;
+        __syncthreads();
 
         if (!NUMERIC) {
 #pragma unroll
@@ -257,8 +325,7 @@ __global__ void __launch_bounds__(WIN_THREADS) k_window(const int32_t* __restric
                 mycount += __popc(bits[w]);
                 bits[w] = 0u;
             }
-            __syncthreads();
-            continue;
+            continue;   // the next win_build_dir starts with a barrier
         }
 
         // ---- rank prefix over the bitmap words ---------------------------------
@@ -267,67 +334,81 @@ __global__ void __launch_bounds__(WIN_THREADS) k_window(const int32_t* __restric
 #pragma unroll
         for (int j = 0; j < WPT; j++) { myw[j] = bits[tid * WPT + j]; s += __popc(myw[j]); }
         int cntw;
-        int ex = block_exclusive_scan<WIN_THREADS, int32_t>(s, sh->tmp, &cntw);
+        const int ex = block_exclusive_scan<THREADS, int32_t>(s, tmp, &cntw);
         {
             int r = ex;
 #pragma unroll
             for (int j = 0; j < WPT; j++) { pre[tid * WPT + j] = (uint32_t)r; r += __popc(myw[j]); }
         }
-        __syncthreads();
-
-        for (int r0 = 0; r0 < cntw; r0 += WIN_VALS) {
-            // column bound of this value sweep: the column holding rank r0 + WIN_VALS
-            const int target = r0 + WIN_VALS;
-            if (target < cntw) {
-                if (ex <= target && target < ex + s) {
-                    int r = ex;
+        const bool staged = cntw <= VALS;
+        for (int r0 = 0; r0 < cntw; r0 += VALS) {
+            const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
+            // ---- value sweep: add the products of ranks [r0, r0+nsub) ----------
+            for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+                if (!single_chunk)
+                    Tc = win_build_dir<THREADS>(c0, lenA, a0, a_ix, winptr, tstride, w0, w1, dir_off, dir_start, tmp);
+                else
+                    __syncthreads();   // pre[] complete / previous output pass done
+                if (Tc == 0) continue;
+                const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+                const int p_lo = wv * per;
+                const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+                int e = 0;
+                for (int pb = p_lo; pb < p_hi; pb += 64 * WIN_U) {
+                    int pos[WIN_U], ent[WIN_U];
+                    bool ok[WIN_U];
 #pragma unroll
-                    for (int j = 0; j < WPT; j++) {
-                        int pc = __popc(myw[j]);
-                        if (r <= target && target < r + pc) {
-                            uint32_t bw = myw[j];
-                            for (int q = target - r; q > 0; q--) bw &= bw - 1u;
-                            sh->cstar = wbase + (tid * WPT + j) * 32 + (__ffs(bw) - 1);
+                    for (int j = 0; j < WIN_U; j++) {
+                        int p = pb + j * 64 + lane;
+                        ok[j] = p < p_hi;
+                        pos[j] = 0;
+                        ent[j] = 0;
+                        if (ok[j]) {
+                            e = win_advance(e, p, dir_off, THREADS);
+                            pos[j] = dir_start[e] + (p - dir_off[e]);
+                            ent[j] = a0 + c0 + e;
                         }
-                        r += pc;
+                    }
+                    int c[WIN_U];
+                    double bv[WIN_U], av[WIN_U];
+#pragma unroll
+                    for (int j = 0; j < WIN_U; j++) {
+                        c[j] = ok[j] ? b_ix[pos[j]] : 0;
+                        bv[j] = ok[j] ? b_val[pos[j]] : 0.0;
+                        av[j] = ok[j] ? a_val[ent[j]] : 0.0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < WIN_U; j++) {
+                        if (ok[j]) {
+                            int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
+                            int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
+                            if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], av[j] * bv[j]);
+                        }
                     }
                 }
-            } else if (tid == 0) {
-                sh->cstar = wend;
             }
             __syncthreads();
-            const int cstar = sh->cstar;
-            // ---- value sweep --------------------------------------------------
-            for (int e = g; e < lenA; e += ngroups) {
-                int4 st = state[a0 + e];
-                if (st.z >= cstar) continue;
-                int cur = st.x;
-                const int end = st.y;
-                const double av = a_val[a0 + e];
-                while (true) {
-                    int idx = cur + t;
-                    bool ok = idx < end;
-                    int c = ok ? b_ix[idx] : KEY_PAD;
-                    ok = ok && c < cstar;
-                    if (ok) {
-                        int w = (c - wbase) >> 5, b = (c - wbase) & 31;
-                        int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
-                        atomicAdd(&vals[r], av * b_val[idx]);
-                    }
-                    int cnt = __popcll((__ballot(ok) >> gshift) & gmask);
-                    cur += cnt;
-                    if (cnt < G) break;
-                }
-                if (t == 0) state[a0 + e] = make_int4(cur, end, cur < end ? b_ix[cur] : KEY_PAD, 0);
-            }
-            __syncthreads();
-            // ---- write out ranks [r0, r0 + nsub) -------------------------------
-            const int nsub = cntw - r0 < WIN_VALS ? cntw - r0 : WIN_VALS;
-            for (int r = tid; r < nsub; r += WIN_THREADS) {
+            // ---- write out ranks [r0, r0+nsub) ------------------------------------
+            for (int r = tid; r < nsub; r += THREADS) {
                 c_val[out + r0 + r] = vals[r];
                 vals[r] = 0.0;
             }
-            {
+            if (staged) {
+                // column ids through LDS (the rank prefix is no longer needed) for coalesced stores
+                int32_t* stage = (int32_t*)pre;
+                int r = ex;
+#pragma unroll
+                for (int j = 0; j < WPT; j++) {
+                    uint32_t bw = myw[j];
+                    const int cbase = wbase + (tid * WPT + j) * 32;
+                    while (bw) {
+                        stage[r++] = cbase + (__ffs(bw) - 1);
+                        bw &= bw - 1u;
+                    }
+                }
+                __syncthreads();
+                for (int r2 = tid; r2 < nsub; r2 += THREADS) c_ix[out + r2] = stage[r2];
+            } else {
                 int r = ex;
 #pragma unroll
                 for (int j = 0; j < WPT; j++) {
@@ -341,18 +422,23 @@ __global__ void __launch_bounds__(WIN_THREADS) k_window(const int32_t* __restric
                     }
                 }
             }
-            __syncthreads();
         }
 #pragma unroll
         for (int j = 0; j < WPT; j++) bits[tid * WPT + j] = 0u;
         out += cntw;
-        __syncthreads();
+        // the next win_build_dir starts with a barrier
     }
     if (!NUMERIC) {
         int tot;
-        block_exclusive_scan<WIN_THREADS, int32_t>(mycount, sh->tmp, &tot);
+        block_exclusive_scan<THREADS, int32_t>(mycount, tmp, &tot);
         if (tid == 0) rowcnt[row] = tot;
     }
+}
+
+template <int THREADS, int WORDS, int VALS, bool NUMERIC>
+constexpr size_t win_lds_bytes() {
+    return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4) + (size_t)(THREADS + 2) * 4 +
+           (size_t)THREADS * 4 + (size_t)(THREADS / 64 + 2) * 4;
 }
 
 // ---------------------------------------------------------------------------
@@ -373,11 +459,6 @@ __global__ void __launch_bounds__(256) k_digest(const int32_t* __restrict__ ix, 
     }
 }
 
-inline size_t win_lds_bytes(bool numeric) {
-    size_t b = numeric ? (size_t)WIN_WORDS_NUM * 8 + (size_t)WIN_VALS * 8 : (size_t)WIN_WORDS_SYM * 4;
-    return b + sizeof(WinShared);
-}
-
 int check_csr_args(const spmm_csr* M) {
     ARGCHK(M != nullptr);
     ARGCHK(M->nrow >= 0 && M->ncol >= 0 && M->nnz >= 0);
@@ -387,18 +468,34 @@ int check_csr_args(const spmm_csr* M) {
     return SPMM_OK;
 }
 
-// Shared front end of symbolic and numeric: P_i, bins, heaviest-first order of the window rows.
+// Shared front end of symbolic and numeric: P_i, bins, heaviest-first order of the window rows,
+// and the window-pointer table of B.  P_i and the table depend only on (A, B) and are kept in the
+// context between calls: symbolic always recomputes them, numeric reuses them when it is called
+// with the same device arrays as the last symbolic call (the normal sequence).
 struct Bins {
     int64_t* prod;
     int32_t *list_s, *list_l, *list_w;
     long long n_s, n_l, n_w, products;
+    int32_t* winptr;
+    int shift, nbase;
 };
 
-int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, bool check_sorted,
+int table_shift(int32_t ncolB) {
+    int shift = WIN_SHIFT_MIN;
+    while (shift < WIN_SHIFT_MAX && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > 256) shift++;
+    return shift;
+}
+
+int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, bool fresh,
                Bins* out) {
     const int32_t nrow = A->nrow;
     long long* counters;
     int ph = phase_begin(ctx, SPMM_PH_BINS);
+    plan_cache& pc = ctx->plan;
+    const bool hit = !fresh && pc.valid && pc.a_ip == A->indptr && pc.a_ix == A->indices && pc.b_ip == B->indptr &&
+                     pc.b_ix == B->indices && pc.a_nrow == A->nrow && pc.b_nrow == B->nrow && pc.b_ncol == B->ncol &&
+                     pc.b_nnz == B->nnz;
+    pc.valid = false;
     CHK(ws(ctx, WS_COUNTERS, CNT_N, &counters));
     CHK(ws(ctx, WS_PROD, (size_t)nrow + 1, &out->prod));
     CHK(ws(ctx, WS_LIST_ESC_S, (size_t)nrow + 1, &out->list_s));
@@ -409,19 +506,27 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_MISC1, (size_t)nrow + 1, &key_w0));
     CHK(ws(ctx, WS_MISC2, (size_t)nrow + 1, &key_w1));
     CHK(ws(ctx, WS_LIST_WIN, (size_t)nrow + 1, &out->list_w));
+    out->shift = table_shift(B->ncol);
+    out->nbase = (int)(((int64_t)B->ncol + (1ll << out->shift) - 1) >> out->shift);
+    if (out->nbase < 1) out->nbase = 1;
+    const size_t table_elems = (size_t)B->nrow * ((size_t)out->nbase + 1);
+    if (table_elems * 4 > ((size_t)96 << 30)) {
+        spmm_set_error("spgemm: window table of B would need %zu GiB", (table_elems * 4) >> 30);
+        return SPMM_E_CAPACITY;
+    }
+    CHK(ws(ctx, WS_WINPTR, table_elems + 1, &out->winptr));
     HIPCHK(hipMemsetAsync(counters, 0, sizeof(long long) * CNT_N, ctx->stream));
-    if (nrow > 0) {
-        int waves_per_block = 4;
-        int64_t nb = ((int64_t)nrow + waves_per_block - 1) / waves_per_block;
+    if (!hit && nrow > 0) {
+        int64_t nb = ((int64_t)nrow + 3) / 4;
         if (nb > 256 * 32) nb = 256 * 32;
         hipLaunchKernelGGL(k_row_products, dim3((unsigned)nb), dim3(256), 0, ctx->stream, nrow, B->nrow, A->indptr,
                            A->indices, B->indptr, out->prod, counters);
-        if (check_sorted && B->nnz > 1) {
-            int64_t g = ((int64_t)B->nnz + 255) / 256;
-            if (g > 256 * 16) g = 256 * 16;
-            hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->nrow, B->indptr,
-                               B->indices, counters);
-        }
+    }
+    if (fresh && B->nnz > 0) {
+        int64_t g = ((int64_t)B->nnz + 255) / 256;
+        if (g > 256 * 16) g = 256 * 16;
+        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->nrow, B->ncol, B->indptr,
+                           B->indices, counters);
     }
     int32_t nr = row_end - row_beg;
     if (nr > 0)
@@ -431,7 +536,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (h[CNT_BAD]) {
-        spmm_set_error("spgemm: a column id of A is outside [0, B.nrow)");
+        spmm_set_error("spgemm: a column id of A is outside [0, B.nrow) or one of B outside [0, B.ncol)");
         return SPMM_E_ARG;
     }
     if (h[CNT_UNSORTED]) {
@@ -444,7 +549,30 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->products = h[CNT_PRODUCTS];
     if (out->n_w > 0)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
+    if (!hit && B->nrow > 0) {
+        int64_t nb = ((int64_t)B->nrow + 3) / 4;
+        if (nb > 256 * 32) nb = 256 * 32;
+        hipLaunchKernelGGL(k_winptr, dim3((unsigned)nb), dim3(256), 0, ctx->stream, B->nrow, B->indptr, B->indices,
+                           out->shift, out->nbase, out->winptr);
+    }
+    pc.a_ip = A->indptr; pc.a_ix = A->indices; pc.b_ip = B->indptr; pc.b_ix = B->indices;
+    pc.a_nrow = A->nrow; pc.b_nrow = B->nrow; pc.b_ncol = B->ncol; pc.b_nnz = B->nnz;
+    pc.valid = true;
     phase_end(ctx, ph);
+    HIPCHK(hipGetLastError());
+    return SPMM_OK;
+}
+
+template <int THREADS, int WORDS, int VALS, bool NUMERIC>
+int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins, int32_t* rowcnt,
+               const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
+    constexpr size_t lds = win_lds_bytes<THREADS, WORDS, VALS, NUMERIC>();
+    static_assert(lds <= 160 * 1024, "LDS budget of one CU");
+    auto kern = k_win<THREADS, WORDS, VALS, NUMERIC>;
+    HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
+                       A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, B->ncol, rowcnt,
+                       c_ip, row_beg, c_ix, c_val);
     return SPMM_OK;
 }
 
@@ -452,14 +580,14 @@ template <bool NUMERIC>
 int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins, int32_t* rowcnt,
                 const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
     if (bins.n_w > 0) {
-        int4* state;
-        CHK(ws(ctx, WS_STATE, (size_t)A->nnz + 1, &state));
-        size_t lds = win_lds_bytes(NUMERIC);
-        HIPCHK(hipFuncSetAttribute((const void*)k_window<NUMERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
-        hipLaunchKernelGGL(k_window<NUMERIC>, dim3((unsigned)bins.n_w), dim3(WIN_THREADS), lds, ctx->stream, bins.list_w,
-                           B->ncol, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, bins.prod, state,
-                           rowcnt, c_ip, row_beg, c_ix, c_val);
+        if (ctx->win_cfg == 1) {
+            if constexpr (NUMERIC) CHK((launch_win<512, 4096, 4096, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<512, 16384, 0, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        } else {
+            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<1024, 32768, 0, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        }
         phase_end(ctx, ph);
     }
     int ph_esc = phase_begin(ctx, NUMERIC ? SPMM_PH_ESC_NUM : SPMM_PH_ESC_SYM);
@@ -488,7 +616,7 @@ extern "C" int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spm
     ARGCHK(A->ncol == B->nrow);
     HIPCHK(hipSetDevice(ctx->device));
     Bins bins;
-    CHK(build_bins(ctx, A, B, 0, A->nrow, false, &bins));
+    CHK(build_bins(ctx, A, B, 0, A->nrow, true, &bins));
     if (prod && A->nrow > 0)
         HIPCHK(hipMemcpyAsync(prod, bins.prod, sizeof(int64_t) * (size_t)A->nrow, hipMemcpyDeviceToDevice, ctx->stream));
     if (total) *total = bins.products;
