@@ -205,6 +205,14 @@ def main():
           [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
            ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN)]}
     ctx.profile(False)
+    stamps = None
+    if os.environ.get("SPMM_WIN_STAMPS") == "1":
+        st = ctx.debug_stamps().astype(np.float64)
+        names = ["directory", "sweep_own", "sweep_wait", "prefix", "value_own", "value_wait", "output", "-", "windows", "products"]
+        stamps = {k: {n: (round(float(v)) if n in ("windows", "products") else round(float(v) / max(st[o:o + 7].sum(), 1), 3))
+                      for n, v in zip(names, st[o:o + 10]) if n != "-"} for k, o in (("symbolic", 0), ("numeric", 16))}
+        stamps["numeric"]["cycles_per_window"] = round(float(st[16:23].sum() / max(st[24], 1)))
+        stamps["symbolic"]["cycles_per_window"] = round(float(st[0:7].sum() / max(st[8], 1)))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nnz_c_local)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -273,6 +281,8 @@ def main():
                            b_allgather_ms=round(b_allgather_ms, 3), setup_s=round(setup_s, 1)),
                phases_ms_per_step={k: round(v[0] / args.steps, 3) for k, v in ph.items()},
                roofline=roofline, cpu_baseline=cpu)
+    if stamps:
+        out["stamps"] = stamps
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -111,6 +111,12 @@ int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, i
  * atomics (exact for integer-valued data below 2^53).  out is a HOST pointer to 2 uint64. */
 int spmm_digest_dev(spmm_ctx* ctx, const int32_t* indices, const double* data, int64_t n, uint64_t* out);
 
+/* Diagnostic (no counterpart in the reference): per-phase shader-cycle sums recorded by the
+ * stamped build of the window kernels, which runs instead of the normal build when the
+ * environment has SPMM_WIN_STAMPS=1 at context creation.  out receives 32 uint64 (HOST pointer):
+ * [0..15] symbolic, [16..31] numeric; see spgemm.hip for the slots. */
+int spmm_debug_stamps(spmm_ctx* ctx, unsigned long long* out, int reset);
+
 #ifdef __cplusplus
 }
 #endif

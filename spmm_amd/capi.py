@@ -118,6 +118,11 @@ class Context:
         _chk(lib().spmm_ctx_phase_ms(self._h, C.c_int(phase), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def debug_stamps(self, reset=True):
+        out = np.zeros(32, np.uint64)
+        _chk(lib().spmm_debug_stamps(self._h, _p(out), C.c_int(1 if reset else 0)))
+        return out
+
     def last_kernel_ms(self):
         return float(lib().spmm_last_kernel_ms(self._h))
 

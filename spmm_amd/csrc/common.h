@@ -43,7 +43,7 @@ void spmm_set_error(const char* fmt, ...);
 enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
     WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
-    WS_WINPTR, WS_SORTKEY, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
+    WS_WINPTR, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     WS_NSLOTS
 };
@@ -60,6 +60,7 @@ struct plan_cache {
 struct spmm_ctx {
     bool profile = false;
     plan_cache plan;
+    bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int win_cfg = 0;   // window-kernel geometry: 0 = 1024 threads, 1 = 512 threads (2 workgroups per CU)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse

@@ -40,6 +40,7 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     }
     c->own_stream = true;
     if (const char* e = getenv("SPMM_WIN_CFG")) c->win_cfg = atoi(e);
+    if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e) != 0;
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
     c->pinned_bytes = 4096;
@@ -99,6 +100,7 @@ int ws_get(spmm_ctx* c, int slot, size_t bytes, void** out) {
         size_t want = bytes + bytes / 8 + 256;
         want = (want + 255) & ~(size_t)255;
         HIPCHK(hipMalloc(&c->slot[slot], want));
+        if (slot == WS_STAMPS) HIPCHK(hipMemsetAsync(c->slot[slot], 0, want, c->stream));
         c->slot_bytes[slot] = want;
     }
     *out = c->slot[slot];

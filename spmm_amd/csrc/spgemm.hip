@@ -200,36 +200,21 @@ __global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __
 // LDS: bitmap of the current column window (WORDS x 32 columns), for numeric also the rank
 // prefix per bitmap word and VALS fp64 accumulators, and a directory of up to THREADS A entries:
 // dir_off[e] = number of products of the entries before e in this window, dir_start[e] = where
-// entry e's part of its B row starts.  A sweep walks the flattened product index space: each
-// wave takes a contiguous range, 64 products per step, finds the entry of a product by a
-// galloping search in dir_off (products are visited in increasing order, so the search starts
-// from the previous hit), and issues U independent loads before it touches the accumulators.
+// entry e's part of its B row starts, dir_av[e] = A's value.  The products of a window form a
+// flat index space; each wave takes a contiguous range of it, 64 products per step, and finds
+// the entry of a product by a galloping search in dir_off that starts from the previous hit.
+//
+// The window width is chosen per row so that a window holds about U*THREADS products.  Such a
+// window is finished in ONE pass over global memory: every lane loads its U products (column,
+// value) into registers, sets their bits, and after the rank prefix adds them from registers.
+// Wider rows (more than THREADS entries) or fuller windows take the general path: a bit sweep
+// and one or more value sweeps that re-read the products.
 template <int THREADS>
-__device__ __forceinline__ int win_build_dir(int c0, int lenA, int a0, const int32_t* __restrict__ a_ix,
-                                             const int32_t* __restrict__ winptr, int64_t tstride, int w0, int w1,
-                                             int32_t* dir_off, int32_t* dir_start, int32_t* tmp) {
-    __syncthreads();   // earlier readers of the directory are done
-    const int e = c0 + (int)threadIdx.x;
-    int s = 0, len = 0;
-    if (e < lenA) {
-        const int32_t* T = winptr + (int64_t)a_ix[a0 + e] * tstride;
-        s = T[w0];
-        len = T[w1] - s;
-    }
-    int tot;
-    int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot);
-    dir_off[threadIdx.x] = off;
-    dir_start[threadIdx.x] = s;
-    if (threadIdx.x == 0) dir_off[THREADS] = tot;
-    __syncthreads();
-    return tot;
-}
-
-// largest e' >= e with dir_off[e'] <= p; requires dir_off[e] <= p < dir_off[nent]
-__device__ __forceinline__ int win_advance(int e, int p, const int32_t* dir_off, int nent) {
+__device__ __forceinline__ int win_advance(int e, int p, const int32_t* dir_off) {
+    // largest e' >= e with dir_off[e'] <= p; requires dir_off[e] <= p < dir_off[THREADS]
     int lo = e, step = 1;
-    while (lo + step < nent && dir_off[lo + step] <= p) { lo += step; step <<= 1; }
-    int hi = lo + step < nent ? lo + step : nent;
+    while (lo + step < THREADS && dir_off[lo + step] <= p) { lo += step; step <<= 1; }
+    int hi = lo + step < THREADS ? lo + step : THREADS;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (dir_off[mid] <= p) lo = mid; else hi = mid;
@@ -237,24 +222,39 @@ __device__ __forceinline__ int win_advance(int e, int p, const int32_t* dir_off,
     return lo;
 }
 
-constexpr int WIN_U = 4;   // independent loads in flight per lane
+// Diagnostic clock read (shader cycles); only instantiated in the STAMP build of k_win.
+__device__ __forceinline__ unsigned long long win_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define WIN_STAMP(i)                                         \
+    if (STAMP && tid == 0) {                                 \
+        unsigned long long now_ = win_clock();               \
+        st_acc[i] += now_ - st_last;                         \
+        st_last = now_;                                      \
+    }
 
-template <int THREADS, int WORDS, int VALS, bool NUMERIC>
+template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP>
 __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                  const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
-                                                 const int32_t* __restrict__ winptr, int nbase, int shift, int32_t ncolB,
-                                                 int32_t* __restrict__ rowcnt, const int64_t* __restrict__ c_ip,
-                                                 int32_t row_beg, int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+                                                 const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                 const int64_t* __restrict__ prod, int32_t* __restrict__ rowcnt,
+                                                 const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val,
+                                                 unsigned long long* __restrict__ stamps) {
     static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
     static_assert(!NUMERIC || VALS <= WORDS, "column staging reuses the rank-prefix array");
+    static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
     constexpr int WPT = WORDS / THREADS;
     constexpr int NW = THREADS / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* bits = (uint32_t*)smem;
     uint32_t* pre = bits + WORDS;                                                       // NUMERIC
     double* vals = (double*)(smem + (size_t)WORDS * 8);                                 // NUMERIC
-    int32_t* dir_off = (int32_t*)(smem + (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4));
+    double* dir_av = (double*)(smem + (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4));
+    int32_t* dir_off = (int32_t*)(dir_av + (NUMERIC ? THREADS : 0));
     int32_t* dir_start = dir_off + THREADS + 2;
     int32_t* tmp = dir_start + THREADS;
 
@@ -265,67 +265,140 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     const int64_t tstride = (int64_t)nbase + 1;
     const bool single_chunk = lenA <= THREADS;
 
-    // base windows per LDS window
+    // base windows per LDS window: about U*THREADS products per window, at most the bitmap width
     int m = (WORDS * 32) >> shift;
-    int64_t out = 0;
     if (NUMERIC) {
-        out = c_ip[row] - c_ip[row_beg];
-        const long long nnz_row = c_ip[row + 1] - c_ip[row];
-        const long long cols_t = nnz_row > 0 ? (long long)(VALS - VALS / 4) * ncolB / nnz_row : (long long)WORDS * 32;
-        while (m > 1 && ((long long)m << shift) > cols_t) m >>= 1;
+        const long long q = prod[row] / nbase;
+        while (m > 1 && q * m > (long long)U * THREADS) m >>= 1;
     }
+    int64_t out = 0;
+    if (NUMERIC) out = c_ip[row] - c_ip[row_beg];
 
+    // single-chunk rows keep their entry's table row and window bounds in registers and fetch
+    // the bound of the NEXT window while the current one is processed
+    const int32_t* T = winptr;
+    int t_lo = 0, t_hi = 0;
+    if (single_chunk && tid < lenA) {
+        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
+        t_lo = T[0];
+        t_hi = T[m < nbase ? m : nbase];
+        if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
+    }
     for (int i = tid; i < WORDS; i += THREADS) bits[i] = 0u;
     if (NUMERIC)
         for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
     int mycount = 0;
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+    if (STAMP && tid == 0) st_last = win_clock();
 
     for (int w0 = 0; w0 < nbase; w0 += m) {
         const int w1 = w0 + m < nbase ? w0 + m : nbase;
         const int wbase = w0 << shift;
-        // ---- bit sweep: one bit per touched column ---------------------------
         long long Tw = 0;
         int Tc = 0;
+        // registers of the one-pass form
+        int cc[U];
+        double pv[U];
+        uint32_t entp[U / 2];   // entry slots of the products, two per word
+        unsigned okm = 0;
+        bool fast = false;
+        // ---- bit sweep: one bit per touched column ---------------------------
         for (int c0 = 0; c0 < lenA; c0 += THREADS) {
-            Tc = win_build_dir<THREADS>(c0, lenA, a0, a_ix, winptr, tstride, w0, w1, dir_off, dir_start, tmp);
+            __syncthreads();   // earlier readers of the directory are done
+            int s = 0, len = 0;
+            if (single_chunk) {
+                if (tid < lenA) {
+                    s = t_lo;
+                    len = t_hi - t_lo;
+                    t_lo = t_hi;
+                    if (w1 < nbase) t_hi = T[w1 + m < nbase ? w1 + m : nbase];
+                }
+            } else {
+                const int e = c0 + tid;
+                if (e < lenA) {
+                    const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                    s = Tp[w0];
+                    len = Tp[w1] - s;
+                    if (NUMERIC) dir_av[tid] = a_val[a0 + e];
+                }
+            }
+            const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
+            dir_off[tid] = off;
+            dir_start[tid] = s;
+            if (tid == 0) dir_off[THREADS] = Tc;
+            __syncthreads();
             Tw += Tc;
+            WIN_STAMP(0)   // directory
             if (Tc == 0) continue;
             const int per = ((Tc + NW - 1) / NW + 63) & ~63;
             const int p_lo = wv * per;
             const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+            fast = NUMERIC && single_chunk && Tc <= U * THREADS;
             int e = 0;
-            for (int pb = p_lo; pb < p_hi; pb += 64 * WIN_U) {
-                int pos[WIN_U];
-                bool ok[WIN_U];
+            if (fast) {
+                int pos[U];
 #pragma unroll
-                for (int j = 0; j < WIN_U; j++) {
-                    int p = pb + j * 64 + lane;
-                    ok[j] = p < p_hi;
+                for (int j = 0; j < U / 2; j++) entp[j] = 0u;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int p = p_lo + j * 64 + lane;
                     pos[j] = 0;
-                    if (ok[j]) {
-                        e = win_advance(e, p, dir_off, THREADS);
+                    if (p < p_hi) {
+                        okm |= 1u << j;
+                        e = win_advance<THREADS>(e, p, dir_off);
                         pos[j] = dir_start[e] + (p - dir_off[e]);
+                        entp[j >> 1] |= (uint32_t)e << ((j & 1) * 16);
                     }
                 }
-                int c[WIN_U];
 #pragma unroll
-                for (int j = 0; j < WIN_U; j++) c[j] = ok[j] ? b_ix[pos[j]] : 0;
+                for (int j = 0; j < U; j++) {
+                    cc[j] = 0;
+                    pv[j] = 0.0;
+                    if (okm & (1u << j)) {
+                        cc[j] = b_ix[pos[j]];
+                        pv[j] = b_val[pos[j]];
+                    }
+                }
 #pragma unroll
-                for (int j = 0; j < WIN_U; j++)
-                    if (ok[j]) atomicOr(&bits[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
+                for (int j = 0; j < U; j++)
+                    if (okm & (1u << j)) atomicOr(&bits[(cc[j] - wbase) >> 5], 1u << ((cc[j] - wbase) & 31));
+            } else {
+                for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
+                    int pos[UG];
+                    unsigned ok = 0;
+#pragma unroll
+                    for (int j = 0; j < UG; j++) {
+                        const int p = pb + j * 64 + lane;
+                        pos[j] = 0;
+                        if (p < p_hi) {
+                            ok |= 1u << j;
+                            e = win_advance<THREADS>(e, p, dir_off);
+                            pos[j] = dir_start[e] + (p - dir_off[e]);
+                        }
+                    }
+                    int c[UG];
+#pragma unroll
+                    for (int j = 0; j < UG; j++) c[j] = (ok & (1u << j)) ? b_ix[pos[j]] : 0;
+#pragma unroll
+                    for (int j = 0; j < UG; j++)
+                        if (ok & (1u << j)) atomicOr(&bits[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
+                }
             }
         }
+        WIN_STAMP(1)   // search + loads + bit atomics (this thread)
         if (Tw == 0) continue;
         __syncthreads();
+        WIN_STAMP(2)   // wait for the other waves
+        if (STAMP && tid == 0) { st_acc[8] += 1; st_acc[9] += (unsigned long long)Tw; }
 
         if (!NUMERIC) {
 #pragma unroll
             for (int j = 0; j < WPT; j++) {
-                int w = tid * WPT + j;
+                const int w = tid * WPT + j;
                 mycount += __popc(bits[w]);
                 bits[w] = 0u;
             }
-            continue;   // the next win_build_dir starts with a barrier
+            continue;   // the next directory build starts with a barrier
         }
 
         // ---- rank prefix over the bitmap words ---------------------------------
@@ -341,53 +414,77 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
             for (int j = 0; j < WPT; j++) { pre[tid * WPT + j] = (uint32_t)r; r += __popc(myw[j]); }
         }
         const bool staged = cntw <= VALS;
+        WIN_STAMP(3)   // rank prefix
         for (int r0 = 0; r0 < cntw; r0 += VALS) {
             const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
-            // ---- value sweep: add the products of ranks [r0, r0+nsub) ----------
-            for (int c0 = 0; c0 < lenA; c0 += THREADS) {
-                if (!single_chunk)
-                    Tc = win_build_dir<THREADS>(c0, lenA, a0, a_ix, winptr, tstride, w0, w1, dir_off, dir_start, tmp);
-                else
-                    __syncthreads();   // pre[] complete / previous output pass done
-                if (Tc == 0) continue;
-                const int per = ((Tc + NW - 1) / NW + 63) & ~63;
-                const int p_lo = wv * per;
-                const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
-                int e = 0;
-                for (int pb = p_lo; pb < p_hi; pb += 64 * WIN_U) {
-                    int pos[WIN_U], ent[WIN_U];
-                    bool ok[WIN_U];
+            if (fast) {
+                __syncthreads();   // rank prefix complete
 #pragma unroll
-                    for (int j = 0; j < WIN_U; j++) {
-                        int p = pb + j * 64 + lane;
-                        ok[j] = p < p_hi;
-                        pos[j] = 0;
-                        ent[j] = 0;
-                        if (ok[j]) {
-                            e = win_advance(e, p, dir_off, THREADS);
-                            pos[j] = dir_start[e] + (p - dir_off[e]);
-                            ent[j] = a0 + c0 + e;
-                        }
+                for (int j = 0; j < U; j++)
+                    if (okm & (1u << j)) {
+                        const int w = (cc[j] - wbase) >> 5, b = (cc[j] - wbase) & 31;
+                        const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u));
+                        atomicAdd(&vals[r], pv[j] * dir_av[(entp[j >> 1] >> ((j & 1) * 16)) & 0xffffu]);
                     }
-                    int c[WIN_U];
-                    double bv[WIN_U], av[WIN_U];
-#pragma unroll
-                    for (int j = 0; j < WIN_U; j++) {
-                        c[j] = ok[j] ? b_ix[pos[j]] : 0;
-                        bv[j] = ok[j] ? b_val[pos[j]] : 0.0;
-                        av[j] = ok[j] ? a_val[ent[j]] : 0.0;
-                    }
-#pragma unroll
-                    for (int j = 0; j < WIN_U; j++) {
-                        if (ok[j]) {
-                            int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
-                            int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
-                            if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], av[j] * bv[j]);
+            } else {
+                // ---- value sweep: add the products of ranks [r0, r0+nsub) ----------
+                for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+                    __syncthreads();   // rank prefix complete / previous output pass done / directory readers done
+                    if (!single_chunk) {
+                        const int e = c0 + tid;
+                        int s2 = 0, len = 0;
+                        if (e < lenA) {
+                            const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                            s2 = Tp[w0];
+                            len = Tp[w1] - s2;
+                            dir_av[tid] = a_val[a0 + e];
                         }
+                        const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
+                        dir_off[tid] = off;
+                        dir_start[tid] = s2;
+                        if (tid == 0) dir_off[THREADS] = Tc;
+                        __syncthreads();
+                    }
+                    if (Tc == 0) continue;
+                    const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+                    const int p_lo = wv * per;
+                    const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+                    int e = 0;
+                    for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
+                        int pos[UG], ent[UG];
+                        unsigned ok = 0;
+#pragma unroll
+                        for (int j = 0; j < UG; j++) {
+                            const int p = pb + j * 64 + lane;
+                            pos[j] = 0;
+                            ent[j] = 0;
+                            if (p < p_hi) {
+                                ok |= 1u << j;
+                                e = win_advance<THREADS>(e, p, dir_off);
+                                pos[j] = dir_start[e] + (p - dir_off[e]);
+                                ent[j] = e;
+                            }
+                        }
+                        int c[UG];
+                        double bv[UG];
+#pragma unroll
+                        for (int j = 0; j < UG; j++) {
+                            c[j] = (ok & (1u << j)) ? b_ix[pos[j]] : 0;
+                            bv[j] = (ok & (1u << j)) ? b_val[pos[j]] : 0.0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < UG; j++)
+                            if (ok & (1u << j)) {
+                                const int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
+                                const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
+                                if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], dir_av[ent[j]] * bv[j]);
+                            }
                     }
                 }
             }
+            WIN_STAMP(4)   // value phase (this thread)
             __syncthreads();
+            WIN_STAMP(5)   // wait for the other waves
             // ---- write out ranks [r0, r0+nsub) ------------------------------------
             for (int r = tid; r < nsub; r += THREADS) {
                 c_val[out + r0 + r] = vals[r];
@@ -415,7 +512,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                     uint32_t bw = myw[j];
                     const int cbase = wbase + (tid * WPT + j) * 32;
                     while (bw) {
-                        int b = __ffs(bw) - 1;
+                        const int b = __ffs(bw) - 1;
                         bw &= bw - 1u;
                         if (r >= r0 && r < r0 + nsub) c_ix[out + r] = cbase + b;
                         r++;
@@ -426,8 +523,11 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
 #pragma unroll
         for (int j = 0; j < WPT; j++) bits[tid * WPT + j] = 0u;
         out += cntw;
-        // the next win_build_dir starts with a barrier
+        WIN_STAMP(6)   // output
+        // the next directory build starts with a barrier
     }
+    if (STAMP && tid == 0)
+        for (int i = 0; i < 10; i++) atomicAdd(&stamps[i], st_acc[i]);
     if (!NUMERIC) {
         int tot;
         block_exclusive_scan<THREADS, int32_t>(mycount, tmp, &tot);
@@ -437,8 +537,8 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
-    return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4) + (size_t)(THREADS + 2) * 4 +
-           (size_t)THREADS * 4 + (size_t)(THREADS / 64 + 2) * 4;
+    return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
+           (size_t)(THREADS + 2) * 4 + (size_t)THREADS * 4 + (size_t)(THREADS / 64 + 2) * 4;
 }
 
 // ---------------------------------------------------------------------------
@@ -563,16 +663,20 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     return SPMM_OK;
 }
 
-template <int THREADS, int WORDS, int VALS, bool NUMERIC>
+template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC>
 int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins, int32_t* rowcnt,
                const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
     constexpr size_t lds = win_lds_bytes<THREADS, WORDS, VALS, NUMERIC>();
+    static_assert(U <= 16, "entry slots are packed two per word and the lane mask has 32 bits");
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
-    auto kern = k_win<THREADS, WORDS, VALS, NUMERIC>;
+    unsigned long long* stamps;
+    CHK(ws(ctx, WS_STAMPS, 32, &stamps));
+    auto kern = ctx->win_stamps ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
+                                : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
-                       A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, B->ncol, rowcnt,
-                       c_ip, row_beg, c_ix, c_val);
+                       A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
+                       c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0));
     return SPMM_OK;
 }
 
@@ -582,11 +686,14 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
     if (bins.n_w > 0) {
         int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
         if (ctx->win_cfg == 1) {
-            if constexpr (NUMERIC) CHK((launch_win<512, 4096, 4096, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<512, 16384, 0, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            if constexpr (NUMERIC) CHK((launch_win<512, 4096, 4096, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<512, 16384, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        } else if (ctx->win_cfg == 2) {
+            if constexpr (NUMERIC) CHK((launch_win<512, 8192, 8192, 16, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<512, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
         } else {
-            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<1024, 32768, 0, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
         }
         phase_end(ctx, ph);
     }
@@ -603,6 +710,22 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
 }
 
 }  // namespace
+
+// Diagnostic: per-phase cycle sums of the window kernels' thread 0 (STAMP build, selected with
+// SPMM_WIN_STAMPS=1 in the environment).  out[0..15] symbolic, out[16..31] numeric:
+// 0 directory, 1 sweep (own), 2 sweep (wait), 3 rank prefix, 4 value phase (own), 5 value phase
+// (wait), 6 output, 8 windows, 9 products.  reset != 0 clears the sums afterwards.
+extern "C" int spmm_debug_stamps(spmm_ctx* ctx, unsigned long long* out, int reset) {
+    ARGCHK(ctx != nullptr && out != nullptr);
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned long long* stamps;
+    CHK(ws(ctx, WS_STAMPS, 32, &stamps));
+    HIPCHK(hipMemcpyAsync(ctx->pinned, stamps, 32 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned, 32 * 8);
+    if (reset) HIPCHK(hipMemsetAsync(stamps, 0, 32 * 8, ctx->stream));
+    return SPMM_OK;
+}
 
 extern "C" void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large) {
     if (esc_small) *esc_small = ESC_S_CAP;
