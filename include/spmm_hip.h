@@ -71,6 +71,12 @@ enum {
     SPMM_PH_ESC_NUM = 4,     /* numeric, expand/sort/compress rows */
     SPMM_PH_SCAN = 5,        /* row-count scan -> C row pointers */
     SPMM_PH_CSR_BUILD = 6,
+    SPMM_PH_REORDER = 7,     /* row keys + stable bucket + row gather (bitmap.h:108) */
+    SPMM_PH_BLOCKS = 8,      /* greedy row blocking (transmat.h:334) */
+    SPMM_PH_PANELS = 9,      /* panel lists + panel sort + grouping (v8sort.h:49,152) */
+    SPMM_PH_PACK = 10,       /* block row gather + 8-row interleave (serial_newblock_clock.cpp:336-399) */
+    SPMM_PH_RENUMBER = 11,   /* first-touch renumbering (serial_newblock_clock.cpp:187) */
+    SPMM_PH_WBSEQ = 12,      /* write-back sequence (wbsort.h) */
     SPMM_PH_COUNT = 32
 };
 int spmm_ctx_profile(spmm_ctx* ctx, int enable);
@@ -88,6 +94,37 @@ int spmm_csr_from_coo(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, co
                       const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
 int spmm_csr_from_coo_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
                           const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
+
+/* ---- the format-generation pipeline: replaces gen_trace_formats(),
+ *      serial_newblock_clock.cpp:221-499, and hands back EVERY array it produces (the reference
+ *      drops the per-block ones, :221 by-value parameters and :363).  All arrays are HOST pointers,
+ *      caller-allocated at the worst-case sizes given; a NULL pointer skips that output.
+ *        first reorder (bitmap.h:108):       seq_bitmap[nrow] (new->old), r_indptr[nrow+1],
+ *                                            r_indices[nnz], r_data[nnz]
+ *        blocking (transmat.h:334):          bsize_list[cap_blocks+1] -> bnum blocks
+ *        panels (v8sort.h:49,152):           panel_ptr[cap_blocks+1] offsets into panel_list
+ *                                            (block b owns panel_ptr[b+1]-panel_ptr[b] entries, one
+ *                                            more than its panels), panel_list[nrow/8+3*cap_blocks+8],
+ *                                            spv8_list[same size] one entry per panel,
+ *                                            out_seq_all[nrow] block-local row ids
+ *        gather + 8-row interleave:          b_indptr[nrow+cap_blocks] (rows+1 block-local entries
+ *                                            per block, concatenated), b_colidx_orig[nnz], b_data[nnz]
+ *        first touch (:187):                 b_local[nnz], keys[nnz] (n_keys used),
+ *                                            seq_offset[cap_blocks+1]
+ *        write-back sequence (wbsort.h):     seq_input[nnz] (n_keys used), rseq[nrow]
+ *      sect is the reference's SECT (2048, :19), threshold its 65536 (transmat.h:339).
+ *      Requires ncol <= nrow (wbsort.h:88 indexes rows by column id).  Panel ties are ordered
+ *      by (length, row id): the reference's std::sort order is unspecified.
+ *      Returns SPMM_E_CAPACITY when more than cap_blocks blocks are needed. */
+typedef struct {
+    int32_t* seq_bitmap; int32_t* r_indptr; int32_t* r_indices; double* r_data;
+    int32_t* bsize_list; int32_t* seq_offset; int32_t cap_blocks;
+    int32_t* panel_ptr; int32_t* panel_list; int32_t* spv8_list;
+    int32_t* out_seq_all; int32_t* b_indptr; int32_t* b_colidx_orig; int32_t* b_local;
+    double* b_data; int32_t* keys; int32_t* seq_input; int32_t* rseq;
+    int32_t bnum; int32_t n_keys; int32_t n_panel_entries; int32_t n_spv8;   /* outputs */
+} spmm_trace;
+int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t threshold, spmm_trace* out);
 
 /* ---- sparse product C = A*B (not present in the reference; implied by wbsort.h:87-88,
  *      where B = A).  B's rows must have ascending column ids (duplicates allowed).

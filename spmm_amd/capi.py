@@ -37,6 +37,15 @@ class CsrView(C.Structure):
                 ("indptr", C.c_void_p), ("indices", C.c_void_p), ("data", C.c_void_p)]
 
 
+class TraceOut(C.Structure):
+    """spmm_trace (include/spmm_hip.h): host arrays of every stage of the pipeline."""
+    _fields_ = [(n, C.c_void_p) for n in ("seq_bitmap", "r_indptr", "r_indices", "r_data", "bsize_list", "seq_offset")] + \
+               [("cap_blocks", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("panel_ptr", "panel_list", "spv8_list", "out_seq_all", "b_indptr",
+                                          "b_colidx_orig", "b_local", "b_data", "keys", "seq_input", "rseq")] + \
+               [(n, C.c_int32) for n in ("bnum", "n_keys", "n_panel_entries", "n_spv8")]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -138,6 +147,32 @@ class Context:
     def csr_from_coo_dev(self, nrow, ncol, nnz, row, col, indptr, indices, data):
         _chk(lib().spmm_csr_from_coo_dev(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), _p(row), _p(col),
                                          _p(indptr), _p(indices), _p(data)))
+
+    # ---- format-generation pipeline (serial_newblock_clock.cpp:221-499) ---------
+    def trace_formats(self, A, sect=2048, threshold=65536, cap_blocks=None):
+        """Returns a dict with every array the pipeline produces (names as in spmm_trace)."""
+        nrow, nnz = A.nrow, A.nnz
+        cap = cap_blocks if cap_blocks is not None else max(1, min(nrow + 1, 1 << 20))
+        a = dict(
+            seq_bitmap=np.empty(nrow, I32), r_indptr=np.empty(nrow + 1, I32), r_indices=np.empty(nnz, I32),
+            r_data=np.empty(nnz, F64), bsize_list=np.empty(cap + 1, I32), seq_offset=np.empty(cap + 1, I32),
+            panel_ptr=np.empty(cap + 1, I32), panel_list=np.empty(nrow // 8 + 3 * cap + 8, I32),
+            spv8_list=np.empty(nrow // 8 + 3 * cap + 8, I32), out_seq_all=np.empty(nrow, I32),
+            b_indptr=np.empty(nrow + cap, I32), b_colidx_orig=np.empty(nnz, I32), b_local=np.empty(nnz, I32),
+            b_data=np.empty(nnz, F64), keys=np.empty(nnz, I32), seq_input=np.empty(nnz, I32), rseq=np.empty(nrow, I32))
+        o = TraceOut()
+        for k, v in a.items():
+            setattr(o, k, v.ctypes.data)
+        o.cap_blocks = cap
+        va = A.view()
+        _chk(lib().spmm_trace_formats(self._h, C.byref(va), C.c_int32(sect), C.c_int32(threshold), C.byref(o)))
+        b, nk = o.bnum, o.n_keys
+        out = dict(a)
+        out.update(bnum=b, bsize_list=a["bsize_list"][:b + 1].copy(), seq_offset=a["seq_offset"][:b + 1].copy(),
+                   panel_ptr=a["panel_ptr"][:b + 1].copy(), panel_list=a["panel_list"][:o.n_panel_entries].copy(),
+                   spv8_list=a["spv8_list"][:o.n_spv8].copy(), b_indptr=a["b_indptr"][:nrow + b].copy(),
+                   keys=a["keys"][:nk].copy(), seq_input=a["seq_input"][:nk].copy())
+        return out
 
     # ---- product -------------------------------------------------------------
     def spgemm_symbolic(self, A, B=None):

@@ -44,7 +44,7 @@ enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
     WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
     WS_WINPTR, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
-    WS_MISC7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
+    WS_MISC7, WS_P0, WS_P1, WS_P2, WS_P3, WS_P4, WS_P5, WS_P6, WS_P7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     WS_NSLOTS
 };
 
@@ -91,6 +91,7 @@ inline int ws(spmm_ctx* ctx, int slot, size_t count, T** out) {
 int dev_exclusive_scan_i32(spmm_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);          // out[n] = total too
 int dev_exclusive_scan_i32_i64(spmm_ctx* ctx, const int32_t* in, int64_t* out, int64_t n);      // out has n+1 entries
 int dev_exclusive_scan_i64(spmm_ctx* ctx, const int64_t* in, int64_t* out, int64_t n);          // out has n+1 entries
+int dev_inclusive_scan_max_i32(spmm_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);      // running maximum, n entries
 // Stable LSD radix sort of (key, value) uint32 pairs on key bits [0, key_bits).  The sorted
 // pairs end in keys_out/vals_out (which must not alias the inputs); inputs are clobbered when
 // more than one pass is needed.  vals may be null on both sides (keys only).

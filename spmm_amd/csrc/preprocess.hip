@@ -1,0 +1,690 @@
+// The reference's format-generation pipeline (gen_trace_formats, serial_newblock_clock.cpp:221-499)
+// as data-parallel HIP kernels for gfx950.  Stage by stage:
+//
+//   row keys + stable bucket + row gather   bitmap.h:108-170        k_row_keys, radix sort, gather
+//   greedy row blocking                     transmat.h:334-376      prev-occurrence + k_block_chain
+//   panel boundaries                        v8sort.h:49-73          k_panel_list (prefix-min form)
+//   per-panel order + 8-row grouping        v8sort.h:152-232        two stable radix sorts + ranks
+//   block row gather + 8-row interleave     serial_newblock_clock.cpp:336-399   gather (fused)
+//   first-touch column renumbering          serial_newblock_clock.cpp:187-204   sort by (col,pos)
+//   write-back / fetch sequence             wbsort.h:16-95          compose / invert / gather
+//
+// Tie rule of the panel sort: stable by (length, block-local row id).  The reference's
+// std::sort (bitmap.h:50) leaves ties in an implementation-defined order; everything that does
+// not depend on ties is identical to it.
+#include "common.h"
+#include <climits>
+
+namespace {
+
+inline unsigned grid_for(int64_t n, int threads, int cap = 256 * 16) {
+    int64_t g = (n + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void k_iota(uint32_t* p, int64_t n) { GRID_STRIDE(i, n) p[i] = (uint32_t)i; }
+
+// upper_bound(a, a+n, v) - 1 : last index whose value is <= v (requires a[0] <= v)
+__device__ __forceinline__ int last_le(const int32_t* __restrict__ a, int n, int v) {
+    int lo = 0, hi = n;   // a[lo] <= v, a[hi] > v (hi == n means none)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// Row key, bitmap.h:123-143: walk the row, sec = col / sect; when the section rises above the
+// previous element's and the running score beats the best, the PREVIOUS section becomes the
+// best and the score restarts (only then); key = best section + 1.  One thread per row.
+__global__ void __launch_bounds__(256) k_row_keys(int32_t nrow, const int32_t* __restrict__ ip,
+                                                  const int32_t* __restrict__ ix, int32_t sect,
+                                                  uint32_t* __restrict__ keys) {
+    GRID_STRIDE(r, nrow) {
+        int best = 0, best_sec = -1, prev_sec = 0, score = 0;
+        const int e = ip[r + 1];
+        for (int p = ip[r]; p < e; p++) {
+            int sec = ix[p] / sect;
+            if (sec > prev_sec && score > best) { best = score; best_sec = prev_sec; score = 0; }
+            prev_sec = sec;
+            score++;
+        }
+        keys[r] = (uint32_t)(best_sec + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row gather: output row t = input row perm[t].  Optional 8-row interleave: when grp[t] = c >= 0
+// the row is the c-th of a group of 8 equal-length rows that starts at output row t - c, and
+// its element r goes to group_start + 8 r + c (serial_newblock_clock.cpp:369-385).
+__global__ void k_perm_lens(int32_t n, const int32_t* __restrict__ perm, const int32_t* __restrict__ ip,
+                            int32_t* __restrict__ lens) {
+    GRID_STRIDE(t, n) { int s = perm[t]; lens[t] = ip[s + 1] - ip[s]; }
+}
+
+constexpr int GR_ROWS = 256;   // output rows per workgroup
+__global__ void __launch_bounds__(256) k_gather_rows(int32_t n, const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ src_ip, const int32_t* __restrict__ src_ix,
+                                                     const double* __restrict__ src_val, const int32_t* __restrict__ dst_ip,
+                                                     int32_t* __restrict__ dst_ix, double* __restrict__ dst_val,
+                                                     const int8_t* __restrict__ grp) {
+    __shared__ int32_t d0[GR_ROWS + 1];
+    __shared__ int32_t s0[GR_ROWS];
+    const int t0 = blockIdx.x * GR_ROWS;
+    const int nr = n - t0 < GR_ROWS ? n - t0 : GR_ROWS;
+    const int base = dst_ip[t0];
+    for (int i = threadIdx.x; i <= nr; i += 256) d0[i] = dst_ip[t0 + i] - base;
+    for (int i = threadIdx.x; i < nr; i += 256) s0[i] = src_ip[perm[t0 + i]];
+    __syncthreads();
+    const int total = d0[nr];
+    for (int p = threadIdx.x; p < total; p += 256) {
+        const int j = last_le(d0, nr, p);        // row of element p (d0[nr] = total > p)
+        const int r = p - d0[j];
+        const int src = s0[j] + r;
+        int dst = base + p;
+        if (grp != nullptr) {
+            const int c = grp[t0 + j];
+            if (c >= 0) dst = dst_ip[t0 + j - c] + 8 * r + c;
+        }
+        dst_ix[dst] = src_ix[src];
+        dst_val[dst] = src_val[src];
+    }
+}
+
+int dev_gather_rows(spmm_ctx* ctx, int32_t n, const int32_t* perm, const int32_t* src_ip, const int32_t* src_ix,
+                    const double* src_val, int32_t* dst_ip, int32_t* dst_ix, double* dst_val, const int8_t* grp) {
+    int32_t* lens;
+    CHK(ws(ctx, WS_MISC0, (size_t)n + 1, &lens));
+    if (n > 0) hipLaunchKernelGGL(k_perm_lens, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, perm, src_ip, lens);
+    CHK(dev_exclusive_scan_i32(ctx, lens, dst_ip, n));
+    if (n > 0)
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + GR_ROWS - 1) / GR_ROWS)), dim3(256), 0, ctx->stream, n, perm,
+                           src_ip, src_ix, src_val, dst_ip, dst_ix, dst_val, grp);
+    HIPCHK(hipGetLastError());
+    return SPMM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// prev[p] = position of the previous occurrence of ix[p]'s column in the stream, or -1.
+// Input: the stream sorted by (column, position).
+__global__ void k_prev_from_sorted(int64_t n, const uint32_t* __restrict__ col_sorted, const uint32_t* __restrict__ pos_sorted,
+                                   int32_t* __restrict__ prev) {
+    GRID_STRIDE(i, n) {
+        int32_t v = -1;
+        if (i > 0 && col_sorted[i - 1] == col_sorted[i]) v = (int32_t)pos_sorted[i - 1];
+        prev[pos_sorted[i]] = v;
+    }
+}
+
+// Greedy blocking, transmat.h:346-362, as one workgroup walking the stream: an element is a new
+// column of the block that starts at stream position s0 iff prev < s0; the block is cut after the
+// row that holds the threshold-th new column.  8192 elements per step.
+constexpr int BC_THREADS = 1024, BC_ITEMS = 8;
+__global__ void __launch_bounds__(BC_THREADS) k_block_chain(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
+                                                            const int32_t* __restrict__ prev, int32_t threshold,
+                                                            int32_t* __restrict__ bsize, int32_t cap,
+                                                            int32_t* __restrict__ result /* [0]=bnum or -1 */) {
+    __shared__ int32_t tmp[BC_THREADS / 64 + 1];
+    __shared__ int32_t cut_pos;
+    const int tid = threadIdx.x;
+    int nb = 1;          // entries written (bsize[0] = 0)
+    if (tid == 0) bsize[0] = 0;
+    int s0 = 0, cnt = 0, p = 0;
+    bool overflow = cap < 2;
+    while (!overflow && p < nnz) {
+        unsigned mask = 0;
+        const int q0 = p + tid * BC_ITEMS;
+#pragma unroll
+        for (int j = 0; j < BC_ITEMS; j++) {
+            int q = q0 + j;
+            if (q < nnz && prev[q] < s0) mask |= 1u << j;
+        }
+        const int c = __popc(mask);
+        int tot;
+        const int ex = block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
+        if (cnt + tot < threshold) {
+            cnt += tot;
+            p += BC_THREADS * BC_ITEMS;
+            continue;
+        }
+        const int target = threshold - cnt;   // 1-based rank of the deciding element in this step
+        if (ex < target && target <= ex + c) {
+            unsigned m = mask;
+            for (int k = target - ex; k > 1; k--) m &= m - 1u;
+            cut_pos = q0 + (__ffs(m) - 1);
+        }
+        __syncthreads();
+        const int r = last_le(r_ip, nrow + 1, cut_pos);   // row holding that element
+        if (nb + 1 >= cap) { overflow = true; break; }
+        if (tid == 0) bsize[nb] = r + 1;
+        nb++;
+        s0 = r_ip[r + 1];
+        cnt = 0;
+        p = s0;
+        __syncthreads();
+    }
+    if (!overflow && nb >= cap) overflow = true;
+    if (tid == 0) {
+        if (overflow) {
+            result[0] = -1;
+        } else {
+            bsize[nb] = nrow;
+            result[0] = nb;   // bnum = entries - 1 = nb
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Panel boundaries of one block, v8sort.h:49-73.  Rows are visited in steps of 8 (step j looks at
+// row 8j); a boundary is pushed at step j when the block-local nnz offset x_j of that row exceeds
+// the running bound (c+1)*ps, c = pushes so far, at most one push per step.  With g_j = number of
+// k >= 1 with x_j > k*ps the recurrence c_{j+1} = min(c_j + 1, g_j) has the closed form
+// c_j = j + min(0, min_{i<j} (g_i - 1 - i)), an exclusive prefix minimum.  One workgroup per block;
+// lists go to a padded layout (offset bsize[b]/8 + 3b), counts[b] = list length.
+__global__ void __launch_bounds__(256) k_panel_list(const int32_t* __restrict__ bsize, const int32_t* __restrict__ r_ip,
+                                                    int32_t* __restrict__ padded, int32_t* __restrict__ counts) {
+    __shared__ int32_t tmp[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int r0 = bsize[b], rows = bsize[b + 1] - r0;
+    const int32_t* ipb = r_ip + r0;
+    const int off = ipb[0];
+    const int nnz = ipb[rows] - off;
+    const int ps = nnz / (rows / 2048 + 1) + 1;
+    int32_t* list = padded + (r0 / 8 + 3 * b);
+    const int steps = (rows + 7) / 8;
+    int carry = 0;   // min(0, min over earlier chunks of h)
+    int c_end = 0;
+    for (int j0 = 0; j0 < steps; j0 += 256) {
+        const int j = j0 + tid;
+        int g = 0, h = INT_MAX;
+        if (j < steps) {
+            int x = ipb[8 * j] - off;
+            g = x > 0 ? (x - 1) / ps : 0;
+            h = g - 1 - j;
+        }
+        // exclusive prefix min of h inside the chunk
+        int inc = h;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_up(inc, d, 64);
+            if ((tid & 63) >= d) inc = o < inc ? o : inc;
+        }
+        __syncthreads();
+        if ((tid & 63) == 63) tmp[tid >> 6] = inc;
+        __syncthreads();
+        int basew = INT_MAX;
+        for (int w = 0; w < (tid >> 6); w++) basew = tmp[w] < basew ? tmp[w] : basew;
+        int prevl = __shfl_up(inc, 1, 64);
+        if ((tid & 63) == 0) prevl = INT_MAX;
+        int exm = prevl < basew ? prevl : basew;      // min over earlier steps of this chunk
+        exm = exm < carry ? exm : carry;
+        const int c = j + exm;                         // pushes before step j
+        if (j < steps && c < g) list[1 + c] = 8 * j;
+        int chunk_min = INT_MAX;
+        for (int w = 0; w < 4; w++) chunk_min = tmp[w] < chunk_min ? tmp[w] : chunk_min;
+        carry = chunk_min < carry ? chunk_min : carry;
+        const int jl = (j0 + 256 < steps ? j0 + 256 : steps);
+        c_end = jl + carry;                            // pushes after the last step of this chunk
+    }
+    if (tid == 0) {
+        list[0] = 0;
+        list[1 + c_end] = rows;
+        counts[b] = c_end + 2;
+    }
+}
+
+__global__ void k_panel_compact(int32_t bnum, const int32_t* __restrict__ bsize, const int32_t* __restrict__ padded,
+                                const int32_t* __restrict__ panel_ptr, int32_t* __restrict__ panel_list,
+                                int32_t* __restrict__ pstart, int32_t* __restrict__ pend, int32_t* __restrict__ pblock) {
+    // one workgroup per block: copy its list, and emit the global row range of each of its panels
+    const int b = blockIdx.x;
+    const int o = panel_ptr[b], n = panel_ptr[b + 1] - o;
+    const int32_t* list = padded + (bsize[b] / 8 + 3 * b);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        panel_list[o + i] = list[i];
+        if (i + 1 < n) {
+            const int pid = o - b + i;
+            pstart[pid] = bsize[b] + list[i];
+            pend[pid] = bsize[b] + list[i + 1];
+            pblock[pid] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Panel sort, v8sort.h:152-232.
+__global__ void k_row_len_pid(int32_t nrow, const int32_t* __restrict__ r_ip, const int32_t* __restrict__ pstart, int32_t npanel,
+                              uint32_t* __restrict__ len, uint32_t* __restrict__ pid, int32_t* __restrict__ maxlen) {
+    GRID_STRIDE(r, nrow) {
+        int l = r_ip[r + 1] - r_ip[r];
+        len[r] = (uint32_t)l;
+        pid[r] = (uint32_t)last_le(pstart, npanel, (int)r);
+        atomicMax(maxlen, l);
+    }
+}
+
+__global__ void k_gather_u32(int64_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+    GRID_STRIDE(i, n) dst[i] = src[idx[i]];
+}
+
+__global__ void k_len_hist(int32_t nrow, const uint32_t* __restrict__ len, const uint32_t* __restrict__ pid, int32_t* __restrict__ cnt) {
+    GRID_STRIDE(r, nrow) if (len[r] < 33u) atomicAdd(&cnt[(int64_t)pid[r] * 33 + len[r]], 1);
+}
+
+// per panel: prefixes over the 33 short lengths.  pre[pid][0..32] = rows shorter than L,
+// gpre = grouped rows of shorter lengths, rpre = leftover rows of shorter lengths; tot = {C32, G, R}
+__global__ void __launch_bounds__(64) k_panel_prefix(int32_t npanel, const int32_t* __restrict__ cnt, int32_t* __restrict__ pre,
+                                                     int32_t* __restrict__ gpre, int32_t* __restrict__ rpre, int32_t* __restrict__ tot,
+                                                     int32_t* __restrict__ spv8) {
+    const int pid = blockIdx.x, L = threadIdx.x;
+    int c = L < 33 ? cnt[(int64_t)pid * 33 + L] : 0;
+    int full = c - c % 8, rem = c % 8;
+    int ic = wave_inclusive_scan(c), ig = wave_inclusive_scan(full), ir = wave_inclusive_scan(rem);
+    if (L < 33) {
+        pre[(int64_t)pid * 33 + L] = ic - c;
+        gpre[(int64_t)pid * 33 + L] = ig - full;
+        rpre[(int64_t)pid * 33 + L] = ir - rem;
+    }
+    if (L == 63) {
+        tot[pid * 3 + 0] = ic;
+        tot[pid * 3 + 1] = ig;
+        tot[pid * 3 + 2] = ir;
+        spv8[pid] = ig;
+    }
+}
+
+// q = position in the (panel, length, row) order; sorted_row[q] = global row.
+__global__ void k_panel_place(int32_t nrow, const uint32_t* __restrict__ sorted_row, const uint32_t* __restrict__ len,
+                              const uint32_t* __restrict__ pid_of_row, const int32_t* __restrict__ pstart,
+                              const int32_t* __restrict__ pblock, const int32_t* __restrict__ bsize,
+                              const int32_t* __restrict__ cnt, const int32_t* __restrict__ pre, const int32_t* __restrict__ gpre,
+                              const int32_t* __restrict__ rpre, const int32_t* __restrict__ tot, int32_t* __restrict__ out_seq,
+                              int8_t* __restrict__ grp) {
+    GRID_STRIDE(q, nrow) {
+        const int row = (int)sorted_row[q];
+        const int pid = (int)pid_of_row[row];
+        const int ps = pstart[pid];
+        const int j = (int)q - ps;
+        const int L = (int)len[row];
+        const int G = tot[pid * 3 + 1], R = tot[pid * 3 + 2], C32 = tot[pid * 3 + 0];
+        int opos, c = -1;
+        if (L < 33) {
+            const int64_t o = (int64_t)pid * 33 + L;
+            const int rho = j - pre[o];
+            const int cn = cnt[o];
+            const int full = cn - cn % 8;
+            if (rho < full) { opos = gpre[o] + rho; c = opos & 7; }
+            else opos = G + rpre[o] + (rho - full);
+        } else {
+            opos = G + R + (j - C32);
+        }
+        out_seq[ps + opos] = row - bsize[pblock[pid]];
+        grp[ps + opos] = (int8_t)c;
+    }
+}
+
+// perm2[t] = global source row of output row t; block-local row pointers per block.
+__global__ void k_perm2(int32_t nrow, const int32_t* __restrict__ out_seq, const int32_t* __restrict__ bsize, int32_t bnum,
+                        int32_t* __restrict__ perm2) {
+    GRID_STRIDE(t, nrow) {
+        int b = last_le(bsize, bnum + 1, (int)t);
+        perm2[t] = bsize[b] + out_seq[t];
+    }
+}
+
+__global__ void k_block_indptr(int32_t bnum, const int32_t* __restrict__ bsize, const int32_t* __restrict__ g_ip,
+                               int32_t* __restrict__ b_indptr) {
+    const int b = blockIdx.x;
+    const int r0 = bsize[b], rows = bsize[b + 1] - r0;
+    const int base = g_ip[r0];
+    for (int j = threadIdx.x; j <= rows; j += blockDim.x) b_indptr[r0 + b + j] = g_ip[r0 + j] - base;
+}
+
+// ---------------------------------------------------------------------------
+// First-touch renumbering, serial_newblock_clock.cpp:187-204, over the whole stream at once.
+__global__ void k_block_nnz_starts(int32_t bnum, const int32_t* __restrict__ bsize, const int32_t* __restrict__ r_ip,
+                                   int32_t* __restrict__ bnnz) {
+    GRID_STRIDE(b, bnum + 1) bnnz[b] = r_ip[bsize[b]];
+}
+
+// in (column, position) order: an element is the first of its column in its block iff its
+// predecessor has another column or lies before the block's first stream position.
+__global__ void k_first_flags(int64_t n, const uint32_t* __restrict__ col_sorted, const uint32_t* __restrict__ pos_sorted,
+                              const int32_t* __restrict__ bnnz, int32_t bnum, int32_t* __restrict__ first /* stream order */,
+                              int32_t* __restrict__ hidx /* sorted order */) {
+    GRID_STRIDE(i, n) {
+        const int pos = (int)pos_sorted[i];
+        bool head = i == 0 || col_sorted[i - 1] != col_sorted[i];
+        if (!head) {
+            const int b = last_le(bnnz, bnum + 1, pos);
+            head = (int)pos_sorted[i - 1] < bnnz[b];
+        }
+        first[pos] = head ? 1 : 0;
+        hidx[i] = head ? (int)i : INT_MIN;
+    }
+}
+
+__global__ void k_renumber(int64_t n, const uint32_t* __restrict__ col_sorted, const uint32_t* __restrict__ pos_sorted,
+                           const int32_t* __restrict__ hrun, const int32_t* __restrict__ gid, const int32_t* __restrict__ bnnz,
+                           int32_t bnum, int32_t* __restrict__ local, int32_t* __restrict__ keys) {
+    GRID_STRIDE(i, n) {
+        const int pos = (int)pos_sorted[i];
+        const int hp = (int)pos_sorted[hrun[i]];       // stream position of the column's first touch in this block
+        const int b = last_le(bnnz, bnum + 1, pos);
+        local[pos] = gid[hp] - gid[bnnz[b]];
+        if (hrun[i] == (int)i) keys[gid[pos]] = (int32_t)col_sorted[i];
+    }
+}
+
+__global__ void k_seq_offset(int32_t bnum, const int32_t* __restrict__ bnnz, const int32_t* __restrict__ gid, int32_t* __restrict__ seq_offset) {
+    GRID_STRIDE(b, bnum + 1) seq_offset[b] = gid[bnnz[b]];
+}
+
+// ---------------------------------------------------------------------------
+// Write-back sequence, wbsort.h:58-67, 16-34, 81-95.
+__global__ void k_rseq(int32_t nrow, const int32_t* __restrict__ seq_bitmap, const int32_t* __restrict__ perm2, int32_t* __restrict__ rseq) {
+    GRID_STRIDE(t, nrow) rseq[seq_bitmap[perm2[t]]] = (int32_t)t;
+}
+__global__ void k_seq_input(int64_t n, const int32_t* __restrict__ keys, const int32_t* __restrict__ rseq, int32_t* __restrict__ seq_input) {
+    GRID_STRIDE(i, n) seq_input[i] = rseq[keys[i]];
+}
+
+// sort the column stream by (column, position); results in WS_RADIX_K1 / WS_RADIX_V1
+int sort_stream_by_col(spmm_ctx* ctx, const int32_t* ix, int32_t nnz, int32_t ncol, uint32_t** col_sorted, uint32_t** pos_sorted) {
+    uint32_t *k0, *v0;
+    CHK(ws(ctx, WS_RADIX_K0, (size_t)nnz + 1, &k0));
+    CHK(ws(ctx, WS_RADIX_V0, (size_t)nnz + 1, &v0));
+    CHK(ws(ctx, WS_RADIX_K1, (size_t)nnz + 1, col_sorted));
+    CHK(ws(ctx, WS_RADIX_V1, (size_t)nnz + 1, pos_sorted));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(k0, ix, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)nnz);
+        CHK(dev_radix_sort_pairs(ctx, k0, v0, *col_sorted, *pos_sorted, nnz, bits_for(ncol > 0 ? (uint32_t)(ncol - 1) : 0u)));
+    }
+    return SPMM_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// device-level stages (all pointers are device pointers)
+
+int dev_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* seq, int32_t* r_ip, int32_t* r_ix, double* r_val) {
+    const int32_t n = A->nrow;
+    int ph = phase_begin(ctx, SPMM_PH_REORDER);
+    uint32_t *k0, *v0, *k1;
+    CHK(ws(ctx, WS_RADIX_K0, (size_t)n + 1, &k0));
+    CHK(ws(ctx, WS_RADIX_V0, (size_t)n + 1, &v0));
+    CHK(ws(ctx, WS_RADIX_K1, (size_t)n + 1, &k1));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, k0);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)n);
+        CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, (uint32_t*)seq, n, bits_for((uint32_t)(A->ncol / sect))));
+    }
+    CHK(dev_gather_rows(ctx, n, seq, A->indptr, A->indices, A->data, r_ip, r_ix, r_val, nullptr));
+    phase_end(ctx, ph);
+    return SPMM_OK;
+}
+
+// bsize: device, cap entries.  *bnum_host receives the number of blocks.
+int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* r_ip, const int32_t* r_ix,
+                   int32_t threshold, int32_t* bsize, int32_t cap, int32_t* bnum_host) {
+    int ph = phase_begin(ctx, SPMM_PH_BLOCKS);
+    uint32_t *cs, *psd;
+    CHK(sort_stream_by_col(ctx, r_ix, nnz, ncol, &cs, &psd));
+    int32_t *prev, *result;
+    CHK(ws(ctx, WS_MISC1, (size_t)nnz + 1, &prev));
+    CHK(ws(ctx, WS_COUNTERS, 64, &result));
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_prev_from_sorted, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, prev);
+    hipLaunchKernelGGL(k_block_chain, dim3(1), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, prev, threshold, bsize, cap, result);
+    int32_t* h = (int32_t*)ctx->pinned;
+    HIPCHK(hipMemcpyAsync(h, result, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    phase_end(ctx, ph);
+    if (h[0] < 0) {
+        spmm_set_error("gen_blocks: more than %d blocks; the block list is too small", cap - 1);
+        return SPMM_E_CAPACITY;
+    }
+    *bnum_host = h[0];
+    return SPMM_OK;
+}
+
+struct PanelsDev {
+    int32_t npanel, n_list;       // host values
+    int32_t *panel_ptr, *panel_list, *pstart, *pend, *pblock, *spv8, *out_seq;
+    int8_t* grp;
+};
+
+// Panel lists, panel sort and grouping.  Outputs panel_ptr[bnum+1], panel_list[<= nrow/8+3*bnum+3],
+// spv8[npanel], out_seq[nrow], grp[nrow] must be preallocated device arrays.
+int dev_panels(spmm_ctx* ctx, int32_t nrow, int32_t bnum, const int32_t* bsize, const int32_t* r_ip, PanelsDev* P) {
+    int ph = phase_begin(ctx, SPMM_PH_PANELS);
+    const size_t padn = (size_t)nrow / 8 + 3 * (size_t)bnum + 8;
+    int32_t *padded, *counts;
+    CHK(ws(ctx, WS_MISC2, padn, &padded));
+    CHK(ws(ctx, WS_MISC3, (size_t)bnum + 1, &counts));
+    hipLaunchKernelGGL(k_panel_list, dim3(bnum), dim3(256), 0, ctx->stream, bsize, r_ip, padded, counts);
+    CHK(dev_exclusive_scan_i32(ctx, counts, P->panel_ptr, bnum));
+    int32_t* h = (int32_t*)ctx->pinned;
+    HIPCHK(hipMemcpyAsync(h, P->panel_ptr + bnum, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    P->n_list = h[0];
+    P->npanel = P->n_list - bnum;
+    const int32_t np = P->npanel;
+    CHK(ws(ctx, WS_MISC4, (size_t)np + 1, &P->pstart));
+    CHK(ws(ctx, WS_MISC5, (size_t)np + 1, &P->pend));
+    CHK(ws(ctx, WS_MISC6, (size_t)np + 1, &P->pblock));
+    hipLaunchKernelGGL(k_panel_compact, dim3(bnum), dim3(256), 0, ctx->stream, bnum, bsize, padded, P->panel_ptr, P->panel_list,
+                       P->pstart, P->pend, P->pblock);
+    // (length, row) then (panel) stable sorts -> (panel, length, row) order
+    uint32_t *len, *pid, *k0, *v0, *k1, *v1;
+    int32_t* maxlen;
+    CHK(ws(ctx, WS_MISC7, (size_t)nrow + 1, &len));
+    CHK(ws(ctx, WS_P0, (size_t)nrow + 1, &pid));
+    CHK(ws(ctx, WS_RADIX_K0, (size_t)nrow + 1, &k0));
+    CHK(ws(ctx, WS_RADIX_V0, (size_t)nrow + 1, &v0));
+    CHK(ws(ctx, WS_RADIX_K1, (size_t)nrow + 1, &k1));
+    CHK(ws(ctx, WS_RADIX_V1, (size_t)nrow + 1, &v1));
+    CHK(ws(ctx, WS_COUNTERS, 64, &maxlen));
+    HIPCHK(hipMemsetAsync(maxlen, 0, 64 * sizeof(int32_t), ctx->stream));
+    if (nrow > 0) {
+        hipLaunchKernelGGL(k_row_len_pid, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, r_ip, P->pstart, np, len, pid, maxlen);
+        HIPCHK(hipMemcpyAsync(h, maxlen, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const int lbits = bits_for((uint32_t)h[0]);
+        HIPCHK(hipMemcpyAsync(k0, len, sizeof(uint32_t) * (size_t)nrow, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)nrow);
+        CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, v1, nrow, lbits));                 // v1 = rows by (len, row)
+        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, (int64_t)nrow, v1, pid, k0);
+        HIPCHK(hipMemcpyAsync(v0, v1, sizeof(uint32_t) * (size_t)nrow, hipMemcpyDeviceToDevice, ctx->stream));
+        CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, v1, nrow, bits_for((uint32_t)(np > 0 ? np - 1 : 0))));   // v1 = (pid, len, row)
+    }
+    int32_t *cnt, *pre, *gpre, *rpre, *tot;
+    CHK(ws(ctx, WS_P1, (size_t)np * 33 + 1, &cnt));
+    CHK(ws(ctx, WS_P2, (size_t)np * 33 + 1, &pre));
+    CHK(ws(ctx, WS_P3, (size_t)np * 33 + 1, &gpre));
+    CHK(ws(ctx, WS_P4, (size_t)np * 33 + 1, &rpre));
+    CHK(ws(ctx, WS_P5, (size_t)np * 3 + 1, &tot));
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)np * 33 + 1), ctx->stream));
+    if (nrow > 0) hipLaunchKernelGGL(k_len_hist, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, len, pid, cnt);
+    if (np > 0) hipLaunchKernelGGL(k_panel_prefix, dim3(np), dim3(64), 0, ctx->stream, np, cnt, pre, gpre, rpre, tot, P->spv8);
+    if (nrow > 0)
+        hipLaunchKernelGGL(k_panel_place, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, v1, len, pid, P->pstart,
+                           P->pblock, bsize, cnt, pre, gpre, rpre, tot, P->out_seq, P->grp);
+    HIPCHK(hipGetLastError());
+    phase_end(ctx, ph);
+    return SPMM_OK;
+}
+
+// gather + interleave: perm2[nrow], g_ip[nrow+1] scratch outputs; b_indptr[nrow+bnum], b_colidx, b_data
+int dev_pack(spmm_ctx* ctx, int32_t nrow, int32_t bnum, const int32_t* bsize, const int32_t* r_ip, const int32_t* r_ix,
+             const double* r_val, const int32_t* out_seq, const int8_t* grp, int32_t* perm2, int32_t* g_ip,
+             int32_t* b_indptr, int32_t* b_colidx, double* b_data) {
+    int ph = phase_begin(ctx, SPMM_PH_PACK);
+    if (nrow > 0) hipLaunchKernelGGL(k_perm2, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, out_seq, bsize, bnum, perm2);
+    CHK(dev_gather_rows(ctx, nrow, perm2, r_ip, r_ix, r_val, g_ip, b_colidx, b_data, grp));
+    hipLaunchKernelGGL(k_block_indptr, dim3(bnum), dim3(256), 0, ctx->stream, bnum, bsize, g_ip, b_indptr);
+    HIPCHK(hipGetLastError());
+    phase_end(ctx, ph);
+    return SPMM_OK;
+}
+
+// first touch: local[nnz], keys[nnz], seq_offset[bnum+1]; *nkeys_host = number of keys
+int dev_first_touch(spmm_ctx* ctx, int32_t ncol, int32_t nnz, int32_t bnum, const int32_t* bsize, const int32_t* r_ip,
+                    const int32_t* stream, int32_t* local, int32_t* keys, int32_t* seq_offset, int32_t* nkeys_host) {
+    int ph = phase_begin(ctx, SPMM_PH_RENUMBER);
+    uint32_t *cs, *psd;
+    CHK(sort_stream_by_col(ctx, stream, nnz, ncol, &cs, &psd));
+    int32_t *bnnz, *first, *hidx, *hrun, *gid;
+    CHK(ws(ctx, WS_MISC3, (size_t)bnum + 2, &bnnz));
+    CHK(ws(ctx, WS_MISC1, (size_t)nnz + 1, &first));
+    CHK(ws(ctx, WS_MISC2, (size_t)nnz + 1, &hidx));
+    CHK(ws(ctx, WS_MISC7, (size_t)nnz + 1, &hrun));
+    CHK(ws(ctx, WS_P6, (size_t)nnz + 2, &gid));
+    hipLaunchKernelGGL(k_block_nnz_starts, dim3(grid_for(bnum + 1, 256)), dim3(256), 0, ctx->stream, bnum, bsize, r_ip, bnnz);
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_first_flags, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, bnnz, bnum, first, hidx);
+    CHK(dev_exclusive_scan_i32(ctx, first, gid, nnz));      // gid[nnz] = number of keys
+    CHK(dev_inclusive_scan_max_i32(ctx, hidx, hrun, nnz));
+    if (nnz > 0)
+        hipLaunchKernelGGL(k_renumber, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, hrun, gid, bnnz,
+                           bnum, local, keys);
+    hipLaunchKernelGGL(k_seq_offset, dim3(grid_for(bnum + 1, 256)), dim3(256), 0, ctx->stream, bnum, bnnz, gid, seq_offset);
+    int32_t* h = (int32_t*)ctx->pinned;
+    HIPCHK(hipMemcpyAsync(h, gid + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *nkeys_host = h[0];
+    HIPCHK(hipGetLastError());
+    phase_end(ctx, ph);
+    return SPMM_OK;
+}
+
+int dev_wbseq(spmm_ctx* ctx, int32_t nrow, const int32_t* seq_bitmap, const int32_t* perm2, const int32_t* keys, int32_t nkeys,
+              int32_t* seq_input, int32_t* rseq) {
+    int ph = phase_begin(ctx, SPMM_PH_WBSEQ);
+    if (nrow > 0) hipLaunchKernelGGL(k_rseq, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, seq_bitmap, perm2, rseq);
+    if (nkeys > 0)
+        hipLaunchKernelGGL(k_seq_input, dim3(grid_for(nkeys, 256)), dim3(256), 0, ctx->stream, (int64_t)nkeys, keys, rseq, seq_input);
+    HIPCHK(hipGetLastError());
+    phase_end(ctx, ph);
+    return SPMM_OK;
+}
+
+// ===========================================================================
+// C ABI: the whole pipeline with host arrays
+namespace {
+template <typename T>
+int dalloc(std::vector<void*>& pool, size_t count, T** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (count + 1) * sizeof(T)) != hipSuccess) {
+        spmm_set_error("hipMalloc of %zu bytes failed", (count + 1) * sizeof(T));
+        return SPMM_E_HIP;
+    }
+    pool.push_back(p);
+    *out = (T*)p;
+    return SPMM_OK;
+}
+struct PoolGuard {
+    std::vector<void*> pool;
+    ~PoolGuard() { for (void* p : pool) hipFree(p); }
+};
+template <typename T>
+int d2h(spmm_ctx* ctx, T* host, const T* dev, size_t count) {
+    if (host && count) HIPCHK(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return SPMM_OK;
+}
+}  // namespace
+
+extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t threshold, spmm_trace* o) {
+    ARGCHK(ctx != nullptr && A != nullptr && o != nullptr);
+    ARGCHK(A->nrow >= 0 && A->ncol >= 0 && A->nnz >= 0 && A->indptr != nullptr);
+    ARGCHK(A->nnz == 0 || (A->indices != nullptr && A->data != nullptr));
+    ARGCHK(sect > 0 && threshold > 0 && o->cap_blocks >= 1);
+    ARGCHK(A->ncol <= A->nrow);   // the write-back sequence indexes rows by column id (wbsort.h:88)
+    HIPCHK(hipSetDevice(ctx->device));
+    const int32_t n = A->nrow, nnz = A->nnz;
+    const size_t z = (size_t)nnz;
+    PoolGuard g;
+    int32_t *a_ip, *a_ix, *seq_bitmap, *r_ip, *r_ix, *bsize;
+    double *a_val, *r_val;
+    CHK(dalloc(g.pool, (size_t)n + 1, &a_ip));
+    CHK(dalloc(g.pool, z, &a_ix));
+    CHK(dalloc(g.pool, z, &a_val));
+    CHK(dalloc(g.pool, (size_t)n, &seq_bitmap));
+    CHK(dalloc(g.pool, (size_t)n + 1, &r_ip));
+    CHK(dalloc(g.pool, z, &r_ix));
+    CHK(dalloc(g.pool, z, &r_val));
+    const int32_t cap = o->cap_blocks + 1;
+    CHK(dalloc(g.pool, (size_t)cap, &bsize));
+    HIPCHK(hipMemcpyAsync(a_ip, A->indptr, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) {
+        HIPCHK(hipMemcpyAsync(a_ix, A->indices, 4 * z, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(a_val, A->data, 8 * z, hipMemcpyHostToDevice, ctx->stream));
+    }
+    spmm_csr dA = *A;
+    dA.indptr = a_ip; dA.indices = a_ix; dA.data = a_val;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    CHK(dev_bitmap_reorder(ctx, &dA, sect, seq_bitmap, r_ip, r_ix, r_val));
+    int32_t bnum = 0;
+    CHK(dev_gen_blocks(ctx, n, A->ncol, nnz, r_ip, r_ix, threshold, bsize, cap, &bnum));
+    PanelsDev P;
+    int8_t* grp;
+    int32_t *perm2, *g_ip, *b_indptr, *b_colidx, *b_local, *keys, *seq_offset, *seq_input, *rseq;
+    double* b_data;
+    CHK(dalloc(g.pool, (size_t)bnum + 1, &P.panel_ptr));
+    CHK(dalloc(g.pool, (size_t)n / 8 + 3 * (size_t)bnum + 8, &P.panel_list));
+    CHK(dalloc(g.pool, (size_t)n / 8 + 3 * (size_t)bnum + 8, &P.spv8));
+    CHK(dalloc(g.pool, (size_t)n, &P.out_seq));
+    CHK(dalloc(g.pool, (size_t)n, &grp));
+    P.grp = grp;
+    CHK(dev_panels(ctx, n, bnum, bsize, r_ip, &P));
+    CHK(dalloc(g.pool, (size_t)n, &perm2));
+    CHK(dalloc(g.pool, (size_t)n + 1, &g_ip));
+    CHK(dalloc(g.pool, (size_t)n + bnum, &b_indptr));
+    CHK(dalloc(g.pool, z, &b_colidx));
+    CHK(dalloc(g.pool, z, &b_data));
+    CHK(dev_pack(ctx, n, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, b_indptr, b_colidx, b_data));
+    CHK(dalloc(g.pool, z, &b_local));
+    CHK(dalloc(g.pool, z, &keys));
+    CHK(dalloc(g.pool, (size_t)bnum + 1, &seq_offset));
+    int32_t nkeys = 0;
+    CHK(dev_first_touch(ctx, A->ncol, nnz, bnum, bsize, r_ip, b_colidx, b_local, keys, seq_offset, &nkeys));
+    CHK(dalloc(g.pool, (size_t)nkeys, &seq_input));
+    CHK(dalloc(g.pool, (size_t)n, &rseq));
+    CHK(dev_wbseq(ctx, n, seq_bitmap, perm2, keys, nkeys, seq_input, rseq));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    // download
+    o->bnum = bnum;
+    o->n_keys = nkeys;
+    o->n_panel_entries = P.n_list;
+    o->n_spv8 = P.npanel;
+    CHK(d2h(ctx, o->seq_bitmap, seq_bitmap, (size_t)n));
+    CHK(d2h(ctx, o->r_indptr, r_ip, (size_t)n + 1));
+    CHK(d2h(ctx, o->r_indices, r_ix, z));
+    CHK(d2h(ctx, o->r_data, r_val, z));
+    CHK(d2h(ctx, o->bsize_list, bsize, (size_t)bnum + 1));
+    CHK(d2h(ctx, o->seq_offset, seq_offset, (size_t)bnum + 1));
+    CHK(d2h(ctx, o->panel_ptr, P.panel_ptr, (size_t)bnum + 1));
+    CHK(d2h(ctx, o->panel_list, P.panel_list, (size_t)P.n_list));
+    CHK(d2h(ctx, o->spv8_list, P.spv8, (size_t)P.npanel));
+    CHK(d2h(ctx, o->out_seq_all, P.out_seq, (size_t)n));
+    CHK(d2h(ctx, o->b_indptr, b_indptr, (size_t)n + bnum));
+    CHK(d2h(ctx, o->b_colidx_orig, b_colidx, z));
+    CHK(d2h(ctx, o->b_local, b_local, z));
+    CHK(d2h(ctx, o->b_data, b_data, z));
+    CHK(d2h(ctx, o->keys, keys, (size_t)nkeys));
+    CHK(d2h(ctx, o->seq_input, seq_input, (size_t)nkeys));
+    CHK(d2h(ctx, o->rseq, rseq, (size_t)n));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_ms = ms;
+    return SPMM_OK;
+}
