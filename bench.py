@@ -27,7 +27,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from spmm_amd import capi  # noqa: E402
+from spmm_amd import capi, shard  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
@@ -98,37 +98,19 @@ def main():
     if world == 1:
         indptr, indices, data = build_csr(ctx, n, n, row, col)
     else:
-        lo, hi = rank * n // world, (rank + 1) * n // world
+        lo, hi = shard.even_row_slice(n, rank, world)
         m = (row >= lo) & (row < hi)
         ip_l, ix_l, _ = build_csr(ctx, hi - lo, n, (row[m] - lo).contiguous(), col[m].contiguous())
-        torch.cuda.synchronize()
-        cnt = torch.tensor([ix_l.numel()], dtype=torch.int64, device=dev)
-        cnts = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(cnts, cnt)
-        cnts_h = cnts.cpu().tolist()
-        mx = max(cnts_h)
-        pad = torch.zeros(mx, dtype=torch.int32, device=dev)
-        pad[:ix_l.numel()] = ix_l
-        rows_max = max((r + 1) * n // world - r * n // world for r in range(world))
-        lens = torch.zeros(rows_max, dtype=torch.int32, device=dev)
-        lens[:hi - lo] = ip_l[1:] - ip_l[:-1]
-        allix = torch.empty(world * mx, dtype=torch.int32, device=dev)
-        alllen = torch.empty(world * rows_max, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        dist.all_gather_into_tensor(allix, pad)
-        dist.all_gather_into_tensor(alllen, lens)
+        indptr, indices = shard.allgather_csr_slices(ip_l, ix_l, n, rank, world, dist)
         e1.record()
         torch.cuda.synchronize()
         b_allgather_ms = e0.elapsed_time(e1)
-        indices = torch.cat([allix[r * mx: r * mx + cnts_h[r]] for r in range(world)])
-        lens_all = torch.cat([alllen[r * rows_max: r * rows_max + ((r + 1) * n // world - r * n // world)] for r in range(world)])
-        indptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-        indptr[1:] = torch.cumsum(lens_all, 0).to(torch.int32)
         data = torch.ones(nnz, dtype=torch.float64, device=dev)
-        del allix, alllen, pad, m
+        del m
         assert int(indptr[-1]) == nnz == indices.numel()
     del row, col
     torch.cuda.synchronize()
@@ -138,10 +120,7 @@ def main():
     P_total = ctx.row_products_dev(vB, vB, prod)
     # rows of A per rank: equal shares of the intermediate products
     cum = torch.cumsum(prod, 0)
-    bounds = [0]
-    for r in range(1, world):
-        bounds.append(int(torch.searchsorted(cum, torch.tensor([P_total * r // world], device=dev, dtype=torch.int64))[0]))
-    bounds.append(n)
+    bounds = shard.product_balanced_bounds(prod, world)
     r_lo, r_hi = bounds[rank], bounds[rank + 1]
     rows_l = r_hi - r_lo
     P_local = int(prod[r_lo:r_hi].sum())

@@ -1,0 +1,203 @@
+// Drop-in replacement of the reference's ./serial (serial_newblock_clock.cpp:501-599):
+//   matrix.txt (one name per line; text from the first '.' is dropped, :36-45)
+//   -> mat/mtx/<name>/<name>.mtx (:535-538)
+//   -> result.txt, truncated at start, one line "<name> <ms>ms" per matrix (:510-512, :565)
+//   -> stdout "----name:<name>----" (:567); exit 1 with a message when result.txt cannot be
+//      opened (:513-516).
+// The in-memory work is done by libspmm_hip.so through its C ABI: spmm_csr_from_coo in place of
+// the tail of csr_matrix() (:78-112) and spmm_trace_formats in place of gen_trace_formats()
+// (:221-499).  There is no CPU path: without a gfx950 GPU the program stops with an error.
+//
+// The time written to result.txt is the GPU time of the pipeline with the matrix resident in
+// device memory (hipEvents around the stages), the counterpart of the reference's sum of stage
+// timers, which starts with the matrix resident in host memory.  With SPMM_HARNESS_SPGEMM=1 the
+// product C = A*A is computed as well and one JSON line per matrix goes to result_spgemm.txt.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/spmm_hip.h"
+
+namespace {
+
+std::string strip_name(const std::string& s) {   // serial_newblock_clock.cpp:36-45
+    std::string out;
+    for (char ch : s) {
+        if (ch == '.') break;
+        out.push_back(ch);
+    }
+    return out;
+}
+
+// MatrixMarket coordinate reader with the reference's semantics (serial_newblock_clock.cpp:47-104):
+// '%' lines skipped, "nrow ncol nnz", then nnz lines of which only the first two integers are used.
+bool read_mtx(const std::string& path, int& nrow, int& ncol, std::vector<int>& row, std::vector<int>& col) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)sz + 1);
+    if (sz > 0 && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); return false; }
+    std::fclose(f);
+    buf[(size_t)sz] = 0;
+    const char* p = buf.data();
+    const char* end = p + sz;
+    auto skip_line = [&]() { while (p < end && *p != '\n') p++; if (p < end) p++; };
+    while (p < end && *p == '%') skip_line();
+    auto next_int = [&](long long& v) -> bool {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+        if (p >= end || *p == '\n') return false;
+        bool neg = false;
+        if (*p == '-') { neg = true; p++; }
+        if (p >= end || *p < '0' || *p > '9') return false;
+        long long x = 0;
+        while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); p++; }
+        v = neg ? -x : x;
+        return true;
+    };
+    long long a, b, c;
+    if (!next_int(a) || !next_int(b) || !next_int(c)) return false;
+    skip_line();
+    nrow = (int)a; ncol = (int)b;
+    row.resize((size_t)c);
+    col.resize((size_t)c);
+    for (long long l = 0; l < c; l++) {
+        while (p < end && (*p == '\n' || *p == '\r')) p++;
+        long long r, cc;
+        if (!next_int(r) || !next_int(cc)) return false;
+        skip_line();
+        row[(size_t)l] = (int)(r - 1);
+        col[(size_t)l] = (int)(cc - 1);
+    }
+    return true;
+}
+
+#define CK(call)                                                              \
+    do {                                                                      \
+        int rc_ = (call);                                                     \
+        if (rc_ != 0) {                                                       \
+            std::cerr << #call << " failed: " << spmm_last_error() << "\n";   \
+            return false;                                                     \
+        }                                                                     \
+    } while (0)
+
+bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, std::ofstream* spg) {
+    const std::string path = "mat/mtx/" + mname + "/" + mname + ".mtx";
+    int nrow = 0, ncol = 0;
+    std::vector<int> row, col;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    if (!read_mtx(path, nrow, ncol, row, col)) {
+        std::cerr << "cannot read " << path << "\n";
+        return false;
+    }
+    auto t1 = std::chrono::high_resolution_clock::now();
+    const int nnz = (int)row.size();
+    std::vector<int> indptr((size_t)nrow + 1), indices((size_t)nnz);
+    std::vector<double> data((size_t)nnz);
+    CK(spmm_csr_from_coo(ctx, nrow, ncol, nnz, row.data(), col.data(), indptr.data(), indices.data(), data.data()));
+    const double ms_csr = spmm_last_kernel_ms(ctx);
+    spmm_csr A{nrow, ncol, nnz, indptr.data(), indices.data(), data.data()};
+
+    // caller-allocated outputs, like main()'s seq / bsize_list / seq_offset (:543-553), but sized
+    // so that no block count overflows them
+    const int cap = nrow + 1;
+    std::vector<int> seq_input((size_t)nnz + 1), rseq((size_t)nrow + 1), bsize((size_t)cap + 1), seq_offset((size_t)cap + 1);
+    spmm_trace tr;
+    std::memset(&tr, 0, sizeof tr);
+    tr.cap_blocks = cap;
+    tr.seq_input = seq_input.data();
+    tr.rseq = rseq.data();
+    tr.bsize_list = bsize.data();
+    tr.seq_offset = seq_offset.data();
+    auto t2 = std::chrono::high_resolution_clock::now();
+    CK(spmm_trace_formats(ctx, &A, 2048, 512 * 1024 / 8, &tr));
+    auto t3 = std::chrono::high_resolution_clock::now();
+    const double ms_gpu = spmm_last_kernel_ms(ctx);
+    const double ms_wall = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    const double ms_read = std::chrono::duration<double, std::milli>(t1 - t0).count();
+
+    outfile << mname << " " << ms_gpu << "ms" << std::endl;
+    std::cout << "----name:" << mname << "----" << std::endl;
+
+    if (spg) {
+        std::vector<int64_t> c_ip((size_t)nrow + 1);
+        int64_t nnz_c = 0, products = 0;
+        CK(spmm_spgemm_symbolic(ctx, &A, &A, c_ip.data(), &nnz_c, &products));
+        const double ms_sym = spmm_last_kernel_ms(ctx);
+        double ms_num = 0.0, sum = 0.0;
+        uint64_t hash = 1469598103934665603ull;
+        const int64_t chunk = 64ll << 20;   // entries of C per numeric call
+        std::vector<int> ci;
+        std::vector<double> cd;
+        for (int r0 = 0; r0 < nrow;) {
+            int r1 = r0 + 1;
+            while (r1 < nrow && c_ip[(size_t)r1 + 1] - c_ip[(size_t)r0] <= chunk) r1++;
+            const int64_t nz = c_ip[(size_t)r1] - c_ip[(size_t)r0];
+            ci.resize((size_t)nz + 1);
+            cd.resize((size_t)nz + 1);
+            CK(spmm_spgemm_numeric(ctx, &A, &A, c_ip.data(), r0, r1, ci.data(), cd.data()));
+            ms_num += spmm_last_kernel_ms(ctx);
+            for (int64_t t = 0; t < nz; t++) {
+                hash = (hash ^ (uint32_t)ci[(size_t)t]) * 1099511628211ull;
+                sum += cd[(size_t)t];
+            }
+            r0 = r1;
+        }
+        char line[1024];
+        std::snprintf(line, sizeof line,
+                      "{\"name\": \"%s\", \"rows\": %d, \"nnz\": %d, \"read_ms\": %.3f, \"csr_build_gpu_ms\": %.3f, "
+                      "\"preprocess_gpu_ms\": %.3f, \"preprocess_wall_ms\": %.3f, \"blocks\": %d, \"products\": %lld, "
+                      "\"nnz_c\": %lld, \"symbolic_gpu_ms\": %.3f, \"numeric_gpu_ms\": %.3f, \"gflops_numeric\": %.2f, "
+                      "\"c_indices_fnv1a64\": \"%016llx\", \"c_value_sum\": %.17g}",
+                      mname.c_str(), nrow, nnz, ms_read, ms_csr, ms_gpu, ms_wall, tr.bnum, (long long)products,
+                      (long long)nnz_c, ms_sym, ms_num, ms_num > 0 ? 2.0 * products / (ms_num * 1e-3) / 1e9 : 0.0,
+                      (unsigned long long)hash, sum);
+        *spg << line << std::endl;
+    }
+    return true;
+}
+
+}  // namespace
+
+int main() {
+    std::vector<std::string> mlist;
+    {
+        std::ifstream file("matrix.txt");
+        std::string s;
+        while (std::getline(file, s)) mlist.push_back(s);
+    }
+    std::ofstream outfile("result.txt");
+    if (!outfile) {
+        std::cout << "result.txt not exist";
+        return 1;
+    }
+    spmm_ctx* ctx = nullptr;
+    int dev = 0;
+    if (const char* e = std::getenv("SPMM_DEVICE")) dev = std::atoi(e);
+    if (spmm_ctx_create(dev, &ctx) != 0) {
+        std::cerr << "no usable MI355X: " << spmm_last_error() << "\n";
+        return 2;
+    }
+    std::ofstream spg_file;
+    std::ofstream* spg = nullptr;
+    if (const char* e = std::getenv("SPMM_HARNESS_SPGEMM")) {
+        if (std::atoi(e) != 0) {
+            spg_file.open("result_spgemm.txt");
+            spg = &spg_file;
+        }
+    }
+    int rc = 0;
+    for (const std::string& line : mlist) {
+        const std::string mname = strip_name(line);
+        if (mname.empty()) continue;
+        if (!process(ctx, mname, outfile, spg)) rc = 3;
+    }
+    spmm_ctx_destroy(ctx);
+    return rc;
+}

@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path's sharding logic.  Each rank builds the CSR of
+its even row slice (with the oracle standing in for the GPU CSR build), the slices are
+all-gathered into B, rows of A are split by product count, each rank computes its rows of C with
+the oracle, and the concatenation must equal the single-process product."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+from spmm_amd import shard, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scale = 10
+        n = 1 << scale
+        row, col = synth.rmat(scale, 8, 4)
+        lo, hi = shard.even_row_slice(n, rank, world)
+        m = (row >= lo) & (row < hi)
+        ip_l, ix_l, _ = orc.csr_from_coo(hi - lo, row[m] - lo, col[m])
+        indptr, indices = shard.allgather_csr_slices(torch.from_numpy(ip_l), torch.from_numpy(ix_l), n, rank, world, dist)
+        ip, ix = indptr.numpy(), indices.numpy()
+        fip, fix, fd = orc.csr_from_coo(n, row, col)
+        assert np.array_equal(ip, fip) and np.array_equal(ix, fix)
+        prod, total = orc.row_products(ip, ix, ip)
+        bounds = shard.product_balanced_bounds(torch.from_numpy(prod), world)
+        assert bounds[0] == 0 and bounds[-1] == n and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        share = prod[bounds[rank]:bounds[rank + 1]].sum()
+        assert abs(share - total / world) <= prod.max()          # balanced up to one row
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        d = np.ones(ix.size)
+        c_ip = orc.spgemm_symbolic(r1 - r0, n, ip[r0:r1 + 1], ix, ip, ix)
+        ci, cd, p_local = orc.spgemm_numeric(n, (ip[r0:r1 + 1], ix, d), (ip, ix, d), c_ip)
+        assert p_local == share
+        # global row pointers: local + exclusive scan of the per-rank nnz(C) (8-byte all-gather)
+        cnt = torch.tensor([int(c_ip[-1])], dtype=torch.int64)
+        cnts = torch.empty(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(cnts, cnt)
+        base = int(cnts[:rank].sum())
+        q.put((rank, r0, r1, base, c_ip, ci, cd))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_product_equals_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n = 1 << 10
+    row, col = synth.rmat(10, 8, 4)
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    c_ip, c_ix, c_d = orc.spgemm(n, (ip, ix, d), (ip, ix, d))
+    for rank, r0, r1, base, l_ip, ci, cd in got:
+        assert base == c_ip[r0]
+        assert np.array_equal(l_ip + base, c_ip[r0:r1 + 1])
+        assert np.array_equal(ci, c_ix[c_ip[r0]:c_ip[r1]]) and np.array_equal(cd, c_d[c_ip[r0]:c_ip[r1]])
+
+
+def test_bounds_edge_cases():
+    assert shard.product_balanced_bounds(torch.zeros(0, dtype=torch.int64), 4) == [0, 0, 0, 0, 0]
+    b = shard.product_balanced_bounds(torch.tensor([0, 0, 100, 0], dtype=torch.int64), 2)
+    assert b[0] == 0 and b[-1] == 4 and b == sorted(b)
+    assert shard.product_balanced_bounds(torch.tensor([5, 5, 5, 5], dtype=torch.int64), 1) == [0, 4]
