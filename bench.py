@@ -168,7 +168,7 @@ def main():
     # ---- warm-up (first one verifies: all-ones inputs => sum of C's values == products) -------
     for w in range(max(args.warmup, 1)):
         vsum, hsum = step(verify=(w == 0))
-        if w == 0:
+        if w == 0 and not os.environ.get("SPMM_WIN_DBG"):
             assert vsum == float(P_local), f"rank {rank}: sum(C) = {vsum} but the rows hold {P_local} products"
     nnz_c_local = state["nnz_c"]
 
@@ -182,16 +182,19 @@ def main():
     dt = time.perf_counter() - t1
     ph = {name: ctx.phase_ms(pid) for name, pid in
           [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
-           ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN)]}
+           ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN),
+           ("window_num_narrow", 13)]}
     ctx.profile(False)
     stamps = None
     if os.environ.get("SPMM_WIN_STAMPS") == "1":
         st = ctx.debug_stamps().astype(np.float64)
-        names = ["directory", "sweep_own", "sweep_wait", "prefix", "value_own", "value_wait", "output", "-", "windows", "products"]
-        stamps = {k: {n: (round(float(v)) if n in ("windows", "products") else round(float(v) / max(st[o:o + 7].sum(), 1), 3))
-                      for n, v in zip(names, st[o:o + 10]) if n != "-"} for k, o in (("symbolic", 0), ("numeric", 16))}
-        stamps["numeric"]["cycles_per_window"] = round(float(st[16:23].sum() / max(st[24], 1)))
-        stamps["symbolic"]["cycles_per_window"] = round(float(st[0:7].sum() / max(st[8], 1)))
+        names = ["directory", "sweep_own", "sweep_wait", "prefix", "value_own", "value_wait", "output_rest", "output_vals", "windows", "products"]
+        stamps = {k: {n: (round(float(v)) if n in ("windows", "products") else round(float(v) / max(st[o:o + 8].sum(), 1), 3))
+                      for n, v in zip(names, st[o:o + 10])} for k, o in (("symbolic", 0), ("numeric", 16))}
+        for nm, sl in (("sweep", 26), ("value", 27), ("dir", 28), ("postvalue", 29), ("stage", 30)):
+            stamps["numeric"][f"skew_{nm}_barrier_cycles_per_window"] = round(float(st[sl] / max(st[24], 1)))
+        stamps["numeric"]["cycles_per_window"] = round(float(st[16:24].sum() / max(st[24], 1)))
+        stamps["symbolic"]["cycles_per_window"] = round(float(st[0:8].sum() / max(st[8], 1)))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nnz_c_local)], dtype=torch.float64, device=dev)
     if dist is not None:

@@ -77,6 +77,7 @@ enum {
     SPMM_PH_PACK = 10,       /* block row gather + 8-row interleave (serial_newblock_clock.cpp:336-399) */
     SPMM_PH_RENUMBER = 11,   /* first-touch renumbering (serial_newblock_clock.cpp:187) */
     SPMM_PH_WBSEQ = 12,      /* write-back sequence (wbsort.h) */
+    SPMM_PH_WINDOW_NUM_NARROW = 13, /* part of SPMM_PH_WINDOW_NUM: rows with at most 1024 entries in A */
     SPMM_PH_COUNT = 32
 };
 int spmm_ctx_profile(spmm_ctx* ctx, int enable);

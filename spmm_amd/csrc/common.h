@@ -61,6 +61,8 @@ struct spmm_ctx {
     bool profile = false;
     plan_cache plan;
     bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
+    int num_cfg = -1;  // numeric window kernel: -1 = k_win; k_num with 0 = 1024 threads, 1 = 2 x 512, 2 = 4 x 256 per CU
+    int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     int win_cfg = 0;   // window-kernel geometry: 0 = 1024 threads, 1 = 512 threads (2 workgroups per CU)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse
@@ -150,6 +152,27 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* tmp, T* total) {
     __syncthreads();
     T base = tmp[w];
     *total = tmp[NW];
+    return base + inc - v;
+}
+// Variant for hot loops: one barrier.  tmp must be a buffer that no thread can still be reading
+// from an earlier call (the caller alternates buffers or has a barrier in between); it holds
+// THREADS/64 elements.  Every thread sums the wave totals itself instead of waiting for a
+// serial pass by one thread.
+template <int THREADS, typename T>
+__device__ __forceinline__ T block_exclusive_scan_1b(T v, T* tmp, T* total) {
+    constexpr int NW = THREADS / 64;
+    T inc = wave_inclusive_scan(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) tmp[w] = inc;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const T x = tmp[i];
+        if (i < w) base += x;
+        tot += x;
+    }
+    *total = tot;
     return base + inc - v;
 }
 #endif

@@ -209,18 +209,47 @@ __global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __
 // value) into registers, sets their bits, and after the rank prefix adds them from registers.
 // Wider rows (more than THREADS entries) or fuller windows take the general path: a bit sweep
 // and one or more value sweeps that re-read the products.
-template <int THREADS>
-__device__ __forceinline__ int win_advance(int e, int p, const int32_t* dir_off) {
-    // largest e' >= e with dir_off[e'] <= p; requires dir_off[e] <= p < dir_off[THREADS]
-    int lo = e, step = 1;
-    while (lo + step < THREADS && dir_off[lo + step] <= p) { lo += step; step <<= 1; }
-    int hi = lo + step < THREADS ? lo + step : THREADS;
+// Directory search.  dir[e] = {offset of entry e's products in the window, start of its segment},
+// dir[n].x = number of products.  win_find: largest e in [0,n) with dir[e].x <= p.
+__device__ __forceinline__ int win_find(const int2* dir, int n, int p) {
+    int lo = 0, hi = n;
     while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (dir_off[mid] <= p) lo = mid; else hi = mid;
+        const int mid = (lo + hi) >> 1;
+        if (dir[mid].x <= p) lo = mid; else hi = mid;
     }
     return lo;
 }
+
+// Per-lane cursor over the directory for increasing product indices.
+template <int THREADS>
+struct WinCursor {
+    int e, off, start, nxt;
+    __device__ __forceinline__ void init(const int2* dir, int p) {
+        e = win_find(dir, THREADS, p);
+        const int2 r = dir[e];
+        off = r.x;
+        start = r.y;
+        nxt = dir[e + 1].x;
+    }
+    // move to the entry holding product p (p >= current offset); returns true when the entry changed
+    __device__ __forceinline__ bool seek(const int2* dir, int p) {
+        if (p < nxt) return false;
+        int steps = 0;
+        do {
+            e++;
+            nxt = dir[e + 1].x;
+            steps++;
+        } while (p >= nxt && steps < 4);
+        if (p >= nxt) {
+            e += win_find(dir + e, THREADS - e, p);
+            nxt = dir[e + 1].x;
+        }
+        const int2 r = dir[e];
+        off = r.x;
+        start = r.y;
+        return true;
+    }
+};
 
 // Diagnostic clock read (shader cycles); only instantiated in the STAMP build of k_win.
 __device__ __forceinline__ unsigned long long win_clock() {
@@ -231,8 +260,8 @@ __device__ __forceinline__ unsigned long long win_clock() {
 #define WIN_STAMP(i)                                         \
     if (STAMP && tid == 0) {                                 \
         unsigned long long now_ = win_clock();               \
-        st_acc[i] += now_ - st_last;                         \
-        st_last = now_;                                      \
+        st_lds[i] += now_ - st_lds[15];                      \
+        st_lds[15] = now_;                                   \
     }
 
 template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP>
@@ -243,7 +272,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                                                  const int64_t* __restrict__ prod, int32_t* __restrict__ rowcnt,
                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val,
-                                                 unsigned long long* __restrict__ stamps) {
+                                                 unsigned long long* __restrict__ stamps, int dbg, int min_len) {
     static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
     static_assert(!NUMERIC || VALS <= WORDS, "column staging reuses the rank-prefix array");
     static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
@@ -254,9 +283,11 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     uint32_t* pre = bits + WORDS;                                                       // NUMERIC
     double* vals = (double*)(smem + (size_t)WORDS * 8);                                 // NUMERIC
     double* dir_av = (double*)(smem + (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4));
-    int32_t* dir_off = (int32_t*)(dir_av + (NUMERIC ? THREADS : 0));
-    int32_t* dir_start = dir_off + THREADS + 2;
-    int32_t* tmp = dir_start + THREADS;
+    int2* dir_buf = (int2*)(dir_av + (NUMERIC ? THREADS : 0));                          // 2 x (THREADS + 1) records
+    int32_t* tmp = (int32_t*)(dir_buf + 2 * (THREADS + 1));                             // 3 scan buffers of NW+1
+    int32_t* tmp_dir = tmp + (NW + 1);
+    int32_t* tmp_pre = tmp + 2 * (NW + 1);
+    int flip = 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = list[blockIdx.x];
@@ -264,6 +295,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
     const bool single_chunk = lenA <= THREADS;
+    if (lenA <= min_len) return;   // those rows belong to k_num (block-uniform exit)
 
     // base windows per LDS window: about U*THREADS products per window, at most the bitmap width
     int m = (WORDS * 32) >> shift;
@@ -271,6 +303,8 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         const long long q = prod[row] / nbase;
         while (m > 1 && q * m > (long long)U * THREADS) m >>= 1;
     }
+    // bitmap words of a window owned by one thread (contiguous): only the words the window covers
+    const int wpt = ((m << shift) >> 5) / THREADS;
     int64_t out = 0;
     if (NUMERIC) out = c_ip[row] - c_ip[row_beg];
 
@@ -288,8 +322,24 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     if (NUMERIC)
         for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
     int mycount = 0;
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
-    if (STAMP && tid == 0) st_last = win_clock();
+    // stamp accumulators live in LDS so that the diagnostic build keeps the register allocation
+    unsigned long long* st_lds = (unsigned long long*)(((uintptr_t)(tmp + 3 * (NW + 1)) + 7) & ~(uintptr_t)7);
+    unsigned long long* st_arr = st_lds + 16;   // 5 x NW arrival times
+    if (STAMP && tid == 0) {
+        for (int i = 0; i < 15; i++) st_lds[i] = 0;
+        st_lds[15] = win_clock();
+    }
+#define WIN_ARRIVE(k) if (STAMP && lane == 0) st_arr[(k) * NW + wv] = win_clock();
+#define WIN_SKEW(k, slot)                                                        \
+    if (STAMP && tid == 0) {                                                     \
+        unsigned long long mn_ = st_arr[(k) * NW], mx_ = mn_;                    \
+        for (int i_ = 1; i_ < NW; i_++) {                                        \
+            unsigned long long x_ = st_arr[(k) * NW + i_];                       \
+            mn_ = x_ < mn_ ? x_ : mn_;                                           \
+            mx_ = x_ > mx_ ? x_ : mx_;                                           \
+        }                                                                        \
+        st_lds[slot] += mx_ - mn_;                                               \
+    }
 
     for (int w0 = 0; w0 < nbase; w0 += m) {
         const int w1 = w0 + m < nbase ? w0 + m : nbase;
@@ -299,12 +349,15 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         // registers of the one-pass form
         int cc[U];
         double pv[U];
-        uint32_t entp[U / 2];   // entry slots of the products, two per word
         unsigned okm = 0;
         bool fast = false;
         // ---- bit sweep: one bit per touched column ---------------------------
+        // Single-chunk rows alternate between two directories, so the build needs no barrier in
+        // front: the other buffer's last readers are at least one barrier behind.
+        flip ^= 1;
+        int2* dir = dir_buf + (single_chunk ? flip * (THREADS + 1) : 0);
         for (int c0 = 0; c0 < lenA; c0 += THREADS) {
-            __syncthreads();   // earlier readers of the directory are done
+            if (!single_chunk) __syncthreads();   // earlier readers of the directory are done
             int s = 0, len = 0;
             if (single_chunk) {
                 if (tid < lenA) {
@@ -322,11 +375,13 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                     if (NUMERIC) dir_av[tid] = a_val[a0 + e];
                 }
             }
-            const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
-            dir_off[tid] = off;
-            dir_start[tid] = s;
-            if (tid == 0) dir_off[THREADS] = Tc;
+            const int off = single_chunk ? block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_dir, &Tc)
+                                         : block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
+            dir[tid] = make_int2(off, s);
+            if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
+            WIN_ARRIVE(2)
             __syncthreads();
+            WIN_SKEW(2, 12)
             Tw += Tc;
             WIN_STAMP(0)   // directory
             if (Tc == 0) continue;
@@ -334,34 +389,40 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
             const int p_lo = wv * per;
             const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
             fast = NUMERIC && single_chunk && Tc <= U * THREADS;
-            int e = 0;
+            if (p_lo >= p_hi) continue;   // this wave has no products in the chunk (wave-uniform)
+            WinCursor<THREADS> cur;
+            cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
             if (fast) {
                 int pos[U];
-#pragma unroll
-                for (int j = 0; j < U / 2; j++) entp[j] = 0u;
+                double av = NUMERIC ? dir_av[cur.e] : 0.0;
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const int p = p_lo + j * 64 + lane;
                     pos[j] = 0;
+                    pv[j] = 0.0;
                     if (p < p_hi) {
                         okm |= 1u << j;
-                        e = win_advance<THREADS>(e, p, dir_off);
-                        pos[j] = dir_start[e] + (p - dir_off[e]);
-                        entp[j >> 1] |= (uint32_t)e << ((j & 1) * 16);
+                        if (cur.seek(dir, p)) av = dir_av[cur.e];
+                        pos[j] = cur.start + (p - cur.off);
+                        pv[j] = av;
                     }
                 }
+                double bv[U];
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     cc[j] = 0;
-                    pv[j] = 0.0;
+                    bv[j] = 0.0;
                     if (okm & (1u << j)) {
                         cc[j] = b_ix[pos[j]];
-                        pv[j] = b_val[pos[j]];
+                        bv[j] = b_val[pos[j]];
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < U; j++)
-                    if (okm & (1u << j)) atomicOr(&bits[(cc[j] - wbase) >> 5], 1u << ((cc[j] - wbase) & 31));
+                    if (okm & (1u << j)) {
+                        atomicOr(&bits[(cc[j] - wbase) >> 5], 1u << ((cc[j] - wbase) & 31));
+                        pv[j] *= bv[j];
+                    }
             } else {
                 for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
                     int pos[UG];
@@ -372,8 +433,8 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                         pos[j] = 0;
                         if (p < p_hi) {
                             ok |= 1u << j;
-                            e = win_advance<THREADS>(e, p, dir_off);
-                            pos[j] = dir_start[e] + (p - dir_off[e]);
+                            cur.seek(dir, p);
+                            pos[j] = cur.start + (p - cur.off);
                         }
                     }
                     int c[UG];
@@ -387,44 +448,61 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         }
         WIN_STAMP(1)   // search + loads + bit atomics (this thread)
         if (Tw == 0) continue;
+        WIN_ARRIVE(0)
         __syncthreads();
+        WIN_SKEW(0, 10)
         WIN_STAMP(2)   // wait for the other waves
-        if (STAMP && tid == 0) { st_acc[8] += 1; st_acc[9] += (unsigned long long)Tw; }
+        if (STAMP && tid == 0) { st_lds[8] += 1; st_lds[9] += (unsigned long long)Tw; }
 
         if (!NUMERIC) {
 #pragma unroll
-            for (int j = 0; j < WPT; j++) {
-                const int w = tid * WPT + j;
-                mycount += __popc(bits[w]);
-                bits[w] = 0u;
-            }
+            for (int j = 0; j < WPT; j++)
+                if (j < wpt) {
+                    const int w = tid * wpt + j;
+                    mycount += __popc(bits[w]);
+                    bits[w] = 0u;
+                }
             continue;   // the next directory build starts with a barrier
         }
 
+        if (dbg & 4) {   // timing experiment: stop after the bit sweep
+#pragma unroll
+            for (int j = 0; j < WPT; j++)
+                if (j < wpt) bits[tid * wpt + j] = 0u;
+            continue;
+        }
         // ---- rank prefix over the bitmap words ---------------------------------
         int s = 0;
         uint32_t myw[WPT];
 #pragma unroll
-        for (int j = 0; j < WPT; j++) { myw[j] = bits[tid * WPT + j]; s += __popc(myw[j]); }
+        for (int j = 0; j < WPT; j++) {
+            myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
+            s += __popc(myw[j]);
+        }
         int cntw;
-        const int ex = block_exclusive_scan<THREADS, int32_t>(s, tmp, &cntw);
-        {
+        const int ex = block_exclusive_scan_1b<THREADS, int32_t>(s, tmp_pre, &cntw);
+        if (!(dbg & 32)) {
             int r = ex;
 #pragma unroll
-            for (int j = 0; j < WPT; j++) { pre[tid * WPT + j] = (uint32_t)r; r += __popc(myw[j]); }
+            for (int j = 0; j < WPT; j++)
+                if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
         }
         const bool staged = cntw <= VALS;
         WIN_STAMP(3)   // rank prefix
         for (int r0 = 0; r0 < cntw; r0 += VALS) {
             const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
             if (fast) {
+                WIN_ARRIVE(1)
                 __syncthreads();   // rank prefix complete
+                WIN_SKEW(1, 11)
+                if (!(dbg & 8))
 #pragma unroll
                 for (int j = 0; j < U; j++)
                     if (okm & (1u << j)) {
                         const int w = (cc[j] - wbase) >> 5, b = (cc[j] - wbase) & 31;
                         const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u));
-                        atomicAdd(&vals[r], pv[j] * dir_av[(entp[j >> 1] >> ((j & 1) * 16)) & 0xffffu]);
+                        if (!(dbg & 1)) atomicAdd(&vals[r], pv[j]);
+                        else if (r == 0x7fffffff) vals[0] = pv[j];
                     }
             } else {
                 // ---- value sweep: add the products of ranks [r0, r0+nsub) ----------
@@ -440,29 +518,32 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                             dir_av[tid] = a_val[a0 + e];
                         }
                         const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
-                        dir_off[tid] = off;
-                        dir_start[tid] = s2;
-                        if (tid == 0) dir_off[THREADS] = Tc;
+                        dir[tid] = make_int2(off, s2);
+                        if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
                         __syncthreads();
                     }
                     if (Tc == 0) continue;
                     const int per = ((Tc + NW - 1) / NW + 63) & ~63;
                     const int p_lo = wv * per;
                     const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
-                    int e = 0;
+                    if (p_lo >= p_hi) continue;
+                    WinCursor<THREADS> cur;
+                    cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
+                    double av = dir_av[cur.e];
                     for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
-                        int pos[UG], ent[UG];
+                        int pos[UG];
+                        double pa[UG];
                         unsigned ok = 0;
 #pragma unroll
                         for (int j = 0; j < UG; j++) {
                             const int p = pb + j * 64 + lane;
                             pos[j] = 0;
-                            ent[j] = 0;
+                            pa[j] = 0.0;
                             if (p < p_hi) {
                                 ok |= 1u << j;
-                                e = win_advance<THREADS>(e, p, dir_off);
-                                pos[j] = dir_start[e] + (p - dir_off[e]);
-                                ent[j] = e;
+                                if (cur.seek(dir, p)) av = dir_av[cur.e];
+                                pos[j] = cur.start + (p - cur.off);
+                                pa[j] = av;
                             }
                         }
                         int c[UG];
@@ -477,40 +558,48 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                             if (ok & (1u << j)) {
                                 const int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
                                 const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
-                                if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], dir_av[ent[j]] * bv[j]);
+                                if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], pa[j] * bv[j]);
                             }
                     }
                 }
             }
             WIN_STAMP(4)   // value phase (this thread)
+            WIN_ARRIVE(3)
             __syncthreads();
+            WIN_SKEW(3, 13)
             WIN_STAMP(5)   // wait for the other waves
             // ---- write out ranks [r0, r0+nsub) ------------------------------------
-            for (int r = tid; r < nsub; r += THREADS) {
-                c_val[out + r0 + r] = vals[r];
-                vals[r] = 0.0;
-            }
+            if (!(dbg & 2))
+                for (int r = tid; r < nsub; r += THREADS) {
+                    c_val[out + r0 + r] = vals[r];
+                    vals[r] = 0.0;
+                }
+            WIN_STAMP(7)   // value store loop
             if (staged) {
                 // column ids through LDS (the rank prefix is no longer needed) for coalesced stores
                 int32_t* stage = (int32_t*)pre;
                 int r = ex;
+                if (!(dbg & 16))
 #pragma unroll
                 for (int j = 0; j < WPT; j++) {
                     uint32_t bw = myw[j];
-                    const int cbase = wbase + (tid * WPT + j) * 32;
+                    const int cbase = wbase + (tid * wpt + j) * 32;
                     while (bw) {
                         stage[r++] = cbase + (__ffs(bw) - 1);
                         bw &= bw - 1u;
                     }
                 }
+                WIN_ARRIVE(4)
                 __syncthreads();
-                for (int r2 = tid; r2 < nsub; r2 += THREADS) c_ix[out + r2] = stage[r2];
+                WIN_SKEW(4, 14)
+                if (!(dbg & 2))
+                    for (int r2 = tid; r2 < nsub; r2 += THREADS) c_ix[out + r2] = stage[r2];
             } else {
                 int r = ex;
 #pragma unroll
                 for (int j = 0; j < WPT; j++) {
                     uint32_t bw = myw[j];
-                    const int cbase = wbase + (tid * WPT + j) * 32;
+                    const int cbase = wbase + (tid * wpt + j) * 32;
                     while (bw) {
                         const int b = __ffs(bw) - 1;
                         bw &= bw - 1u;
@@ -521,13 +610,14 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
             }
         }
 #pragma unroll
-        for (int j = 0; j < WPT; j++) bits[tid * WPT + j] = 0u;
+        for (int j = 0; j < WPT; j++)
+            if (j < wpt) bits[tid * wpt + j] = 0u;
         out += cntw;
         WIN_STAMP(6)   // output
         // the next directory build starts with a barrier
     }
     if (STAMP && tid == 0)
-        for (int i = 0; i < 10; i++) atomicAdd(&stamps[i], st_acc[i]);
+        for (int i = 0; i < 15; i++) atomicAdd(&stamps[i], st_lds[i]);
     if (!NUMERIC) {
         int tot;
         block_exclusive_scan<THREADS, int32_t>(mycount, tmp, &tot);
@@ -535,10 +625,288 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     }
 }
 
+// ---------------------------------------------------------------------------
+// Numeric phase for window rows: the same algorithm as k_win<NUMERIC>, kept small so that several
+// workgroups fit a CU and overlap each other's memory and barrier waits: no branches inside the
+// per-product loops (lanes past the end of a wave's slice repeat its last product with a zero bit
+// mask / a zero addend), nothing kept in registers across phases except the U products of a
+// register-resident window.  Rows with at most THREADS entries in A use one directory per window
+// (two buffers, alternating, entry bounds prefetched one window ahead); wider rows rebuild the
+// directory per chunk of THREADS entries and take the two-sweep form.
+template <int THREADS, int WORDS, int VALS, int U, int MINW>
+__global__ void __launch_bounds__(THREADS, MINW) k_num(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                       const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                       const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
+                                                       const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                       const int64_t* __restrict__ prod, const int64_t* __restrict__ c_ip,
+                                                       int32_t row_beg, int32_t* __restrict__ c_ix,
+                                                       double* __restrict__ c_val) {
+    static_assert(WORDS % THREADS == 0 && VALS <= WORDS && U * THREADS <= VALS, "geometry");
+    constexpr int WPT = WORDS / THREADS;
+    constexpr int NW = THREADS / 64;
+    constexpr int CAP = U * THREADS;
+    constexpr int UG = 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* bits = (uint32_t*)smem;
+    uint32_t* pre = bits + WORDS;
+    double* vals = (double*)(smem + (size_t)WORDS * 8);
+    double* dir_av = vals + VALS;
+    int2* dir_buf = (int2*)(dir_av + THREADS);           // 2 x (THREADS + 1)
+    int32_t* tmp_a = (int32_t*)(dir_buf + 2 * (THREADS + 1));
+    int32_t* tmp_b = tmp_a + NW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const bool single = lenA <= THREADS;
+    const int64_t tstride = (int64_t)nbase + 1;
+
+    int m = (WORDS * 32) >> shift;
+    {
+        const long long q = prod[row] / nbase;
+        while (m > 1 && q * m > (long long)CAP) m >>= 1;
+    }
+    const int wpt = ((m << shift) >> 5) / THREADS;
+    int64_t out = c_ip[row] - c_ip[row_beg];
+
+    const int32_t* T = winptr;
+    int t_lo = 0, t_hi = 0;
+    if (single && tid < lenA) {
+        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
+        t_lo = T[0];
+        t_hi = T[m < nbase ? m : nbase];
+        dir_av[tid] = a_val[a0 + tid];
+    }
+    for (int i = tid; i < WORDS; i += THREADS) bits[i] = 0u;
+    for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
+    int flip = 0;
+
+    for (int w0 = 0; w0 < nbase; w0 += m) {
+        const int w1 = w0 + m < nbase ? w0 + m : nbase;
+        const int wbase = w0 << shift;
+        flip ^= 1;
+        int2* dir = dir_buf + (single ? flip * (THREADS + 1) : 0);
+        long long Tw = 0;
+        int Tc = 0, p_lo = 0, p_hi = 0;
+        bool one = false;
+        int cc[U];
+        double pv[U];
+        // ---- bit sweep -------------------------------------------------------
+        for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+            int s = 0, len = 0;
+            if (single) {
+                s = t_lo;
+                len = t_hi - t_lo;
+                t_lo = t_hi;
+                if (tid < lenA && w1 < nbase) t_hi = T[w1 + m < nbase ? w1 + m : nbase];
+            } else {
+                __syncthreads();   // readers of the previous chunk's directory are done
+                const int e = c0 + tid;
+                if (e < lenA) {
+                    const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                    s = Tp[w0];
+                    len = Tp[w1] - s;
+                    dir_av[tid] = a_val[a0 + e];
+                }
+            }
+            const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
+            dir[tid] = make_int2(off, s);
+            if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
+            __syncthreads();
+            Tw += Tc;
+            if (Tc == 0) continue;
+            const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+            p_lo = wv * per;
+            p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+            one = single && Tc <= CAP;          // block-uniform: the window stays in registers
+            if (p_lo >= p_hi) continue;         // wave-uniform
+            WinCursor<THREADS> cur;
+            cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
+            double av = dir_av[cur.e];
+            if (one) {
+                int pos[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int p = p_lo + j * 64 + lane;
+                    const bool valid = p < p_hi;
+                    const int pc = valid ? p : p_hi - 1;
+                    if (cur.seek(dir, pc)) av = dir_av[cur.e];
+                    pos[j] = cur.start + (pc - cur.off);
+                    pv[j] = av;
+                }
+                double bv[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    cc[j] = b_ix[pos[j]];
+                    bv[j] = b_val[pos[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const bool valid = p_lo + j * 64 + lane < p_hi;
+                    atomicOr(&bits[(cc[j] - wbase) >> 5], valid ? 1u << ((cc[j] - wbase) & 31) : 0u);
+                    pv[j] = valid ? pv[j] * bv[j] : 0.0;
+                }
+            } else {
+                for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
+                    int pos[UG];
+#pragma unroll
+                    for (int j = 0; j < UG; j++) {
+                        const int p = pb + j * 64 + lane;
+                        const int pc = p < p_hi ? p : p_hi - 1;
+                        cur.seek(dir, pc);
+                        pos[j] = cur.start + (pc - cur.off);
+                    }
+                    int c[UG];
+#pragma unroll
+                    for (int j = 0; j < UG; j++) c[j] = b_ix[pos[j]];
+#pragma unroll
+                    for (int j = 0; j < UG; j++)   // a repeated product sets a bit that is set anyway
+                        atomicOr(&bits[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
+                }
+            }
+        }
+        if (Tw == 0) continue;
+        __syncthreads();
+        // ---- rank prefix -------------------------------------------------------
+        int cntw;
+        {
+            uint32_t myw[WPT];
+            int sum = 0;
+#pragma unroll
+            for (int j = 0; j < WPT; j++) {
+                myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
+                sum += __popc(myw[j]);
+            }
+            int r = block_exclusive_scan_1b<THREADS, int32_t>(sum, tmp_b, &cntw);
+#pragma unroll
+            for (int j = 0; j < WPT; j++)
+                if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
+        }
+        const bool staged = cntw <= VALS;
+        for (int r0 = 0; r0 < cntw; r0 += VALS) {
+            const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
+            // ---- value phase ---------------------------------------------------
+            if (one) {
+                __syncthreads();   // rank prefix complete
+                if (p_lo < p_hi) {
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int w = (cc[j] - wbase) >> 5, b = (cc[j] - wbase) & 31;
+                        const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u));
+                        atomicAdd(&vals[r], pv[j]);
+                    }
+                }
+            } else {
+                for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+                    __syncthreads();   // rank prefix complete / previous output done / directory readers done
+                    if (!single) {
+                        const int e = c0 + tid;
+                        int s = 0, len = 0;
+                        if (e < lenA) {
+                            const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                            s = Tp[w0];
+                            len = Tp[w1] - s;
+                            dir_av[tid] = a_val[a0 + e];
+                        }
+                        const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
+                        dir[tid] = make_int2(off, s);
+                        if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
+                        __syncthreads();
+                        if (Tc == 0) continue;
+                        const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+                        p_lo = wv * per;
+                        p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+                    }
+                    if (p_lo >= p_hi) continue;
+                    WinCursor<THREADS> cur;
+                    cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
+                    double av = dir_av[cur.e];
+                    for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
+                        int pos[UG];
+                        double pa[UG];
+#pragma unroll
+                        for (int j = 0; j < UG; j++) {
+                            const int p = pb + j * 64 + lane;
+                            const int pc = p < p_hi ? p : p_hi - 1;
+                            if (cur.seek(dir, pc)) av = dir_av[cur.e];
+                            pos[j] = cur.start + (pc - cur.off);
+                            pa[j] = av;
+                        }
+                        int c[UG];
+                        double bv[UG];
+#pragma unroll
+                        for (int j = 0; j < UG; j++) {
+                            c[j] = b_ix[pos[j]];
+                            bv[j] = b_val[pos[j]];
+                        }
+#pragma unroll
+                        for (int j = 0; j < UG; j++) {
+                            const int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
+                            const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
+                            const bool valid = pb + j * 64 + lane < p_hi;
+                            if (valid && (unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], pa[j] * bv[j]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- write out ranks [r0, r0+nsub) ------------------------------------
+            for (int r = tid; r < nsub; r += THREADS) {
+                c_val[out + r0 + r] = vals[r];
+                vals[r] = 0.0;
+            }
+            if (staged) {
+                // column ids through LDS (the rank prefix is no longer needed) for coalesced stores
+                int32_t* stage = (int32_t*)pre;
+                int r = (int)pre[tid * wpt];
+                uint32_t myw[WPT];
+#pragma unroll
+                for (int j = 0; j < WPT; j++) myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
+                __syncthreads();   // every thread has read its rank base before the array is reused
+#pragma unroll
+                for (int j = 0; j < WPT; j++) {
+                    uint32_t bw = myw[j];
+                    const int cbase = wbase + (tid * wpt + j) * 32;
+                    while (bw) {
+                        stage[r++] = cbase + (__ffs(bw) - 1);
+                        bw &= bw - 1u;
+                    }
+                }
+                __syncthreads();
+                for (int r2 = tid; r2 < nsub; r2 += THREADS) c_ix[out + r2] = stage[r2];
+            } else {
+                int r = (int)pre[tid * wpt];
+#pragma unroll
+                for (int j = 0; j < WPT; j++) {
+                    uint32_t bw = j < wpt ? bits[tid * wpt + j] : 0u;
+                    const int cbase = wbase + (tid * wpt + j) * 32;
+                    while (bw) {
+                        const int b = __ffs(bw) - 1;
+                        bw &= bw - 1u;
+                        if (r >= r0 && r < r0 + nsub) c_ix[out + r] = cbase + b;
+                        r++;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; j++)
+            if (j < wpt) bits[tid * wpt + j] = 0u;
+        out += cntw;
+        if (!single) __syncthreads();   // the cleared bitmap and the directory are free for the next window
+    }
+}
+
+template <int THREADS, int WORDS, int VALS>
+constexpr size_t num_lds_bytes() {
+    return (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 + (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64) * 8 + 16;
+}
+
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
     return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
-           (size_t)(THREADS + 2) * 4 + (size_t)THREADS * 4 + (size_t)(THREADS / 64 + 2) * 4;
+           (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8;
 }
 
 // ---------------------------------------------------------------------------
@@ -580,9 +948,11 @@ struct Bins {
     int shift, nbase;
 };
 
-int table_shift(int32_t ncolB) {
+int table_shift(int32_t ncolB, int cfg, int num_cfg) {
+    if (cfg == 3) return 14;
+    if (num_cfg == 2) cfg = 4;   // a 256-thread numeric workgroup holds 64 Ki columns
     int shift = WIN_SHIFT_MIN;
-    while (shift < WIN_SHIFT_MAX && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > 256) shift++;
+    while (shift < (cfg == 4 ? 16 : WIN_SHIFT_MAX) && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > 256) shift++;
     return shift;
 }
 
@@ -606,7 +976,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_MISC1, (size_t)nrow + 1, &key_w0));
     CHK(ws(ctx, WS_MISC2, (size_t)nrow + 1, &key_w1));
     CHK(ws(ctx, WS_LIST_WIN, (size_t)nrow + 1, &out->list_w));
-    out->shift = table_shift(B->ncol);
+    out->shift = table_shift(B->ncol, ctx->win_cfg, ctx->num_cfg);
     out->nbase = (int)(((int64_t)B->ncol + (1ll << out->shift) - 1) >> out->shift);
     if (out->nbase < 1) out->nbase = 1;
     const size_t table_elems = (size_t)B->nrow * ((size_t)out->nbase + 1);
@@ -671,12 +1041,41 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
+    const bool lean = NUMERIC && ctx->num_cfg >= 0 && ctx->win_cfg == 0 && !ctx->win_stamps && !ctx->win_dbg;
     auto kern = ctx->win_stamps ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!lean)
     hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
                        A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
-                       c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0));
+                       c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
+                       -1);
+    if (lean) {
+        int phw = phase_begin(ctx, SPMM_PH_WINDOW_NUM_NARROW);
+        if (ctx->num_cfg == 1) {          // two 512-thread workgroups per CU
+            constexpr size_t nl = num_lds_bytes<512, 4096, 4096>();
+            static_assert(2 * nl <= 160 * 1024, "two workgroups per CU");
+            auto kn = k_num<512, 4096, 4096, 8, 4>;
+            HIPCHK(hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl));
+            hipLaunchKernelGGL(kn, dim3((unsigned)bins.n_w), dim3(512), nl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
+                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
+        } else if (ctx->num_cfg == 2) {   // four 256-thread workgroups per CU
+            constexpr size_t nl = num_lds_bytes<256, 2048, 2048>();
+            static_assert(4 * nl <= 160 * 1024, "four workgroups per CU");
+            auto kn = k_num<256, 2048, 2048, 8, 4>;
+            HIPCHK(hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl));
+            hipLaunchKernelGGL(kn, dim3((unsigned)bins.n_w), dim3(256), nl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
+                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
+        } else {
+            constexpr size_t nl = num_lds_bytes<1024, 8192, 8192>();
+            static_assert(nl <= 160 * 1024, "LDS budget of one CU");
+            auto kn = k_num<1024, 8192, 8192, 8, 4>;
+            HIPCHK(hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl));
+            hipLaunchKernelGGL(kn, dim3((unsigned)bins.n_w), dim3(1024), nl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
+                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
+        }
+        phase_end(ctx, phw);
+    }
     return SPMM_OK;
 }
 
@@ -688,6 +1087,18 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         if (ctx->win_cfg == 1) {
             if constexpr (NUMERIC) CHK((launch_win<512, 4096, 4096, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
             else CHK((launch_win<512, 16384, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        } else if (ctx->win_cfg == 5) {   // six products per lane
+            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 6, 2, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        } else if (ctx->win_cfg == 6) {   // four products per lane
+            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 4, 2, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        } else if (ctx->win_cfg == 3) {   // one wave per row, 16 K-column windows
+            if constexpr (NUMERIC) CHK((launch_win<64, 512, 512, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<64, 2048, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        } else if (ctx->win_cfg == 4) {   // 256 threads, four workgroups per CU
+            if constexpr (NUMERIC) CHK((launch_win<256, 2048, 2048, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            else CHK((launch_win<256, 8192, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
         } else if (ctx->win_cfg == 2) {
             if constexpr (NUMERIC) CHK((launch_win<512, 8192, 8192, 16, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
             else CHK((launch_win<512, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
