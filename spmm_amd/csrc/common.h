@@ -61,6 +61,7 @@ struct spmm_ctx {
     bool profile = false;
     plan_cache plan;
     bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
+    int dense_min = 2048;   // rows with at least this many products per table window use k_dense; 0 = off
     int num_cfg = -1;  // numeric window kernel: -1 = k_win; k_num with 0 = 1024 threads, 1 = 2 x 512, 2 = 4 x 256 per CU
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     int win_cfg = 0;   // window-kernel geometry: 0 = 1024 threads, 1 = 512 threads (2 workgroups per CU)

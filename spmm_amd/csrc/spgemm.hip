@@ -24,11 +24,11 @@ namespace {
 
 constexpr int ESC_S_CAP = 512;
 constexpr int ESC_L_CAP = 4096;
-constexpr int WIN_SHIFT_MIN = 15;       // base column window of the table: 2^15 .. 2^17 columns
+constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14 .. 2^17 columns
 constexpr int WIN_SHIFT_MAX = 17;
 constexpr int KEY_PAD = 0x7fffffff;
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_N = 8 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_N = 8 };
 
 // ---------------------------------------------------------------------------
 // P_i per row, one wave per row.
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol
 __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_end, const int64_t* __restrict__ prod,
                                                   int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
                                                   int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
-                                                  long long* __restrict__ counters) {
+                                                  long long dense_thr, long long* __restrict__ counters) {
     int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
     if (row < row_end) {
@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_e
             int at = (int)atomicAdd((unsigned long long*)&counters[CNT_WIN], 1ull);
             list_w[at] = (int32_t)row;
             key_w[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);   // ascending key = descending P
+            if (p >= dense_thr) atomicAdd((unsigned long long*)&counters[CNT_DENSE], 1ull);
         } else if (p > ESC_S_CAP) {
             list_l[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_L], 1ull)] = (int32_t)row;
         } else if (p > 0) {
@@ -299,9 +300,10 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
 
     // base windows per LDS window: about U*THREADS products per window, at most the bitmap width
     int m = (WORDS * 32) >> shift;
+    const int m_min = (THREADS * 32) >> shift > 1 ? (THREADS * 32) >> shift : 1;   // every thread owns at least one word
     if (NUMERIC) {
         const long long q = prod[row] / nbase;
-        while (m > 1 && q * m > (long long)U * THREADS) m >>= 1;
+        while (m > m_min && q * m > (long long)U * THREADS) m >>= 1;
     }
     // bitmap words of a window owned by one thread (contiguous): only the words the window covers
     const int wpt = ((m << shift) >> 5) / THREADS;
@@ -495,15 +497,18 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                 WIN_ARRIVE(1)
                 __syncthreads();   // rank prefix complete
                 WIN_SKEW(1, 11)
-                if (!(dbg & 8))
+                if (!(dbg & 8)) {
+                    // all rank look-ups first: LDS reads cannot move across the atomics, so one loop
+                    // would pay a full LDS round trip per product
 #pragma unroll
-                for (int j = 0; j < U; j++)
-                    if (okm & (1u << j)) {
-                        const int w = (cc[j] - wbase) >> 5, b = (cc[j] - wbase) & 31;
-                        const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u));
-                        if (!(dbg & 1)) atomicAdd(&vals[r], pv[j]);
-                        else if (r == 0x7fffffff) vals[0] = pv[j];
+                    for (int j = 0; j < U; j++) {
+                        const int cj = (okm & (1u << j)) ? cc[j] - wbase : 0;
+                        cc[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u));
                     }
+#pragma unroll
+                    for (int j = 0; j < U; j++)
+                        if ((okm & (1u << j)) && !(dbg & 1)) atomicAdd(&vals[cc[j]], pv[j]);
+                }
             } else {
                 // ---- value sweep: add the products of ranks [r0, r0+nsub) ----------
                 for (int c0 = 0; c0 < lenA; c0 += THREADS) {
@@ -554,12 +559,13 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                             bv[j] = (ok & (1u << j)) ? b_val[pos[j]] : 0.0;
                         }
 #pragma unroll
+                        for (int j = 0; j < UG; j++) {   // rank look-ups before any atomic (see above)
+                            const int cj = (ok & (1u << j)) ? c[j] - wbase : 0;
+                            c[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u)) - r0;
+                        }
+#pragma unroll
                         for (int j = 0; j < UG; j++)
-                            if (ok & (1u << j)) {
-                                const int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
-                                const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
-                                if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], pa[j] * bv[j]);
-                            }
+                            if ((ok & (1u << j)) && (unsigned)c[j] < (unsigned)nsub) atomicAdd(&vals[c[j]], pa[j] * bv[j]);
                     }
                 }
             }
@@ -664,8 +670,9 @@ __global__ void __launch_bounds__(THREADS, MINW) k_num(const int32_t* __restrict
 
     int m = (WORDS * 32) >> shift;
     {
+        const int m_min = (THREADS * 32) >> shift > 1 ? (THREADS * 32) >> shift : 1;   // every thread owns at least one word
         const long long q = prod[row] / nbase;
-        while (m > 1 && q * m > (long long)CAP) m >>= 1;
+        while (m > m_min && q * m > (long long)CAP) m >>= 1;
     }
     const int wpt = ((m << shift) >> 5) / THREADS;
     int64_t out = c_ip[row] - c_ip[row_beg];
@@ -790,12 +797,14 @@ __global__ void __launch_bounds__(THREADS, MINW) k_num(const int32_t* __restrict
             if (one) {
                 __syncthreads();   // rank prefix complete
                 if (p_lo < p_hi) {
+                    // all rank look-ups first: LDS reads cannot move across the atomics
 #pragma unroll
                     for (int j = 0; j < U; j++) {
-                        const int w = (cc[j] - wbase) >> 5, b = (cc[j] - wbase) & 31;
-                        const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u));
-                        atomicAdd(&vals[r], pv[j]);
+                        const int cj = cc[j] - wbase;
+                        cc[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u));
                     }
+#pragma unroll
+                    for (int j = 0; j < U; j++) atomicAdd(&vals[cc[j]], pv[j]);
                 }
             } else {
                 for (int c0 = 0; c0 < lenA; c0 += THREADS) {
@@ -842,10 +851,13 @@ __global__ void __launch_bounds__(THREADS, MINW) k_num(const int32_t* __restrict
                         }
 #pragma unroll
                         for (int j = 0; j < UG; j++) {
-                            const int w = (c[j] - wbase) >> 5, b = (c[j] - wbase) & 31;
-                            const int r = (int)pre[w] + __popc(bits[w] & ((1u << b) - 1u)) - r0;
+                            const int cj = c[j] - wbase;
+                            c[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u)) - r0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < UG; j++) {
                             const bool valid = pb + j * 64 + lane < p_hi;
-                            if (valid && (unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], pa[j] * bv[j]);
+                            if (valid && (unsigned)c[j] < (unsigned)nsub) atomicAdd(&vals[c[j]], pa[j] * bv[j]);
                         }
                     }
                 }
@@ -898,6 +910,228 @@ __global__ void __launch_bounds__(THREADS, MINW) k_num(const int32_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Numeric phase for the product-heaviest rows: dense accumulators.  A window is DENSE_COLS
+// columns of C held as fp64 sums in LDS plus one flag byte per column; every product is read
+// once and added with ds_add_f64, and the output pass walks the flags in column order, so the
+// row comes out sorted.  The sweep has no workgroup barrier: each wave owns chunks of E entries
+// of the A row (E = 16/32/64 by row length, so that short rows still occupy all waves) and maps
+// products to lanes in three tiers: the first 64/E products of every entry by the lanes of that
+// entry, entries with up to 128 further products by 16-lane groups, longer ones by the whole
+// wave.  Rows with at most 16*E entries keep (table row, value, window bound) in registers.
+// When the table windows are wider than DENSE_COLS the window is swept once per sub-range and
+// products outside the sub-range are skipped.
+constexpr int DENSE_COLS = 16384;
+
+__device__ __forceinline__ void dense_add(double* acc, uint8_t* flags, int col, int cbase, double v) {
+    const unsigned lc = (unsigned)(col - cbase);
+    if (lc < (unsigned)DENSE_COLS) {
+        atomicAdd(&acc[lc], v);
+        flags[lc] = 1;
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                   const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                   const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
+                                                   const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                   const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg) {
+    constexpr int NW = THREADS / 64;
+    static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* acc = (double*)smem;
+    uint8_t* flags = (uint8_t*)(acc + DENSE_COLS);
+    int32_t* tmp = (int32_t*)(flags + DENSE_COLS);   // two scan buffers of NW, used alternately
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    // E entries per wave and pass; entry (pass c, lane el) of wave wv is (c*E + el)*NW + wv, so the
+    // long rows of B that cluster at low column ids spread over all waves
+    const int lgE = dbg ? dbg : lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
+    const int E = 1 << lgE, LA = 64 >> lgE;
+    const int npass = (lenA + E * NW - 1) / (E * NW);
+    const bool cached = npass == 1;
+    const int el = lane & (E - 1), pi = lane >> lgE;
+    const int nsub = shift > 14 ? 1 << (shift - 14) : 1;
+    const bool pipelined = cached && nsub == 1;
+    int64_t out = c_ip[row] - c_ip[row_beg];
+
+    for (int i = tid; i < DENSE_COLS; i += THREADS) acc[i] = 0.0;
+    for (int i = tid; i < DENSE_COLS / 4; i += THREADS) ((uint32_t*)flags)[i] = 0u;
+
+    const int32_t* Tp = winptr;
+    double av = 0.0;
+    int t_cur = 0, t_nxt = 0;
+    bool have = false;
+    // tier-1 products of the coming window, loaded one window ahead (pipelined rows)
+    int pc0 = 0, pc1 = 0;
+    double pb0 = 0.0, pb1 = 0.0;
+    if (cached) {
+        const int e = el * NW + wv;
+        have = e < lenA;
+        if (have) {
+            Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+            av = a_val[a0 + e];
+            t_cur = Tp[0];
+            t_nxt = Tp[1];
+        }
+        if (pipelined) {
+            const int len = t_nxt - t_cur;
+            if (pi < len) { pc0 = b_ix[t_cur + pi]; pb0 = b_val[t_cur + pi]; }
+            if (pi + LA < len) { pc1 = b_ix[t_cur + pi + LA]; pb1 = b_val[t_cur + pi + LA]; }
+        }
+    }
+    __syncthreads();
+
+    int flip = 0;
+    for (int w = 0; w < nbase; w++) {
+        int s_c = 0, len_c = 0;
+        if (cached) {
+            s_c = t_cur;
+            len_c = t_nxt - t_cur;
+            t_cur = t_nxt;
+            if (have && w + 2 <= nbase) t_nxt = Tp[w + 2];   // bound of the next window, used one iteration later
+        }
+        for (int sub = 0; sub < nsub; sub++) {
+            const int cbase = (w << shift) + sub * DENSE_COLS;
+            // ---- sweep ---------------------------------------------------------
+            for (int c = 0; c < npass; c++) {
+                int s = s_c, len = len_c;
+                double a = av;
+                if (!cached) {
+                    const int e = ((c << lgE) + el) * NW + wv;
+                    len = 0;
+                    if (e < lenA) {
+                        const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                        s = Tq[w];
+                        len = Tq[w + 1] - s;
+                        a = a_val[a0 + e];
+                    }
+                }
+                // tier 1: products pi and pi+LA of the lane's own entry
+                if (pipelined) {
+                    if (pi < len) dense_add(acc, flags, pc0, cbase, a * pb0);
+                    if (pi + LA < len) dense_add(acc, flags, pc1, cbase, a * pb1);
+                } else {
+                    const bool v0 = pi < len, v1 = pi + LA < len;
+                    const int q0 = v0 ? b_ix[s + pi] : -1;
+                    const double r0 = v0 ? b_val[s + pi] : 0.0;
+                    const int q1 = v1 ? b_ix[s + pi + LA] : -1;
+                    const double r1 = v1 ? b_val[s + pi + LA] : 0.0;
+                    if (v0) dense_add(acc, flags, q0, cbase, a * r0);
+                    if (v1) dense_add(acc, flags, q1, cbase, a * r1);
+                }
+                const int rem = lane < E ? len - 2 * LA : 0;
+                unsigned long long mask_c = __ballot(rem > 128);
+                unsigned long long mask_b = __ballot(rem > 0 && rem <= 128);
+                // tier 2: 16 lanes per entry, four entries at a time
+                const int nb = __popcll(mask_b);
+                const int g = lane >> 4, sl = lane & 15;
+                for (int it = 0; it < nb; it += 4) {
+                    int l4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        l4[q] = mask_b ? __ffsll(mask_b) - 1 : 0;
+                        mask_b &= mask_b - 1;
+                    }
+                    const int src = g == 0 ? l4[0] : g == 1 ? l4[1] : g == 2 ? l4[2] : l4[3];
+                    // every lane takes part in the shuffles: a masked-off source lane would read as 0
+                    const int ss = __shfl(s, src, 64) + 2 * LA;
+                    const int rsrc = __shfl(rem, src, 64);
+                    const double aa = __shfl(a, src, 64);
+                    const int rr = it + g < nb ? rsrc : 0;
+                    for (int i = sl; i < rr; i += 32) {
+                        const bool v1 = i + 16 < rr;
+                        const int c0 = b_ix[ss + i];
+                        const double b0 = b_val[ss + i];
+                        const int c1 = v1 ? b_ix[ss + i + 16] : -1;
+                        const double b1 = v1 ? b_val[ss + i + 16] : 0.0;
+                        dense_add(acc, flags, c0, cbase, aa * b0);
+                        if (v1) dense_add(acc, flags, c1, cbase, aa * b1);
+                    }
+                }
+                // tier 3: the whole wave on one entry
+                while (mask_c) {
+                    const int src = __ffsll(mask_c) - 1;
+                    mask_c &= mask_c - 1;
+                    const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
+                    const int rr = __builtin_amdgcn_readlane(rem, src);
+                    const double aa = readlane_f64(a, src);
+                    for (int i = lane; i < rr; i += 256) {
+                        int cq[4];
+                        double bq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const bool v = i + 64 * q < rr;
+                            cq[q] = v ? b_ix[ss + i + 64 * q] : -1;
+                            bq[q] = v ? b_val[ss + i + 64 * q] : 0.0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (i + 64 * q < rr) dense_add(acc, flags, cq[q], cbase, aa * bq[q]);
+                    }
+                }
+            }
+            if (pipelined && w + 1 < nbase) {
+                // tier-1 loads of the next window stay in flight across the output pass
+                const int len = t_nxt - t_cur;
+                if (pi < len) { pc0 = b_ix[t_cur + pi]; pb0 = b_val[t_cur + pi]; }
+                if (pi + LA < len) { pc1 = b_ix[t_cur + pi + LA]; pb1 = b_val[t_cur + pi + LA]; }
+            }
+            __syncthreads();
+            // ---- output: thread t owns columns [16t, 16t+16) of the window ----------------
+            const uint4 f = ((const uint4*)flags)[tid];
+            // flag bytes are 0 or 1: the multiply gathers the four low bits of a word into bits 24..27
+            const unsigned m16 = (((f.x * 0x01020408u) >> 24) & 0xfu) | ((((f.y * 0x01020408u) >> 24) & 0xfu) << 4) |
+                                 ((((f.z * 0x01020408u) >> 24) & 0xfu) << 8) | ((((f.w * 0x01020408u) >> 24) & 0xfu) << 12);
+            // sums leave LDS (and the slots are cleared) before the scan barrier, so the next sweep
+            // can start right after it
+            double vr[16];
+            if (m16) {
+                ((uint4*)flags)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                unsigned mm = m16;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    if (mm) {
+                        const int lc = tid * 16 + __ffs(mm) - 1;
+                        mm &= mm - 1u;
+                        vr[i] = acc[lc];
+                        acc[lc] = 0.0;
+                    }
+                }
+            }
+            flip ^= NW;
+            int total;
+            int r = block_exclusive_scan_1b<THREADS, int32_t>(__popc(m16), tmp + flip, &total);
+            if (m16) {
+                unsigned mm = m16;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    if (mm) {
+                        const int lc = tid * 16 + __ffs(mm) - 1;
+                        mm &= mm - 1u;
+                        c_ix[out + r + i] = cbase + lc;
+                        c_val[out + r + i] = vr[i];
+                    }
+                }
+            }
+            out += total;
+        }
+    }
+}
+
+constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * 8; }
+
 template <int THREADS, int WORDS, int VALS>
 constexpr size_t num_lds_bytes() {
     return (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 + (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64) * 8 + 16;
@@ -943,16 +1177,19 @@ int check_csr_args(const spmm_csr* M) {
 struct Bins {
     int64_t* prod;
     int32_t *list_s, *list_l, *list_w;
-    long long n_s, n_l, n_w, products;
+    long long n_s, n_l, n_w, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
 };
 
-int table_shift(int32_t ncolB, int cfg, int num_cfg) {
+int table_shift(int32_t ncolB, int cfg, int num_cfg, int dense_min) {
     if (cfg == 3) return 14;
     if (num_cfg == 2) cfg = 4;   // a 256-thread numeric workgroup holds 64 Ki columns
-    int shift = WIN_SHIFT_MIN;
-    while (shift < (cfg == 4 ? 16 : WIN_SHIFT_MAX) && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > 256) shift++;
+    // with dense rows enabled the table is as fine as the dense accumulators (2^14 columns) up to
+    // 1024 windows; otherwise 2^15 columns up to 256 windows
+    int shift = dense_min > 0 ? WIN_SHIFT_MIN : 15;
+    const int max_windows = dense_min > 0 ? 1024 : 256;
+    while (shift < (cfg == 4 ? 16 : WIN_SHIFT_MAX) && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > max_windows) shift++;
     return shift;
 }
 
@@ -976,7 +1213,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_MISC1, (size_t)nrow + 1, &key_w0));
     CHK(ws(ctx, WS_MISC2, (size_t)nrow + 1, &key_w1));
     CHK(ws(ctx, WS_LIST_WIN, (size_t)nrow + 1, &out->list_w));
-    out->shift = table_shift(B->ncol, ctx->win_cfg, ctx->num_cfg);
+    out->shift = table_shift(B->ncol, ctx->win_cfg, ctx->num_cfg, ctx->dense_min);
     out->nbase = (int)(((int64_t)B->ncol + (1ll << out->shift) - 1) >> out->shift);
     if (out->nbase < 1) out->nbase = 1;
     const size_t table_elems = (size_t)B->nrow * ((size_t)out->nbase + 1);
@@ -999,9 +1236,12 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
                            B->indices, counters);
     }
     int32_t nr = row_end - row_beg;
+    // rows with at least dense_min products per table window on average use dense accumulators
+    long long dense_thr = ctx->dense_min > 0 ? (long long)ctx->dense_min * out->nbase : 0x7fffffffffffffffll;
+    if (ctx->dense_min > 0 && dense_thr > 0xffffffffll) dense_thr = 0xffffffffll;   // the sort key saturates there
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, row_beg, row_end,
-                           out->prod, out->list_s, out->list_l, list_w0, key_w0, counters);
+                           out->prod, out->list_s, out->list_l, list_w0, key_w0, dense_thr, counters);
     long long* h = (long long*)ctx->pinned;
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1016,6 +1256,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->n_s = h[CNT_ESC_S];
     out->n_l = h[CNT_ESC_L];
     out->n_w = h[CNT_WIN];
+    out->n_dense = h[CNT_DENSE];
     out->products = h[CNT_PRODUCTS];
     if (out->n_w > 0)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
@@ -1080,8 +1321,21 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
 }
 
 template <bool NUMERIC>
-int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins, int32_t* rowcnt,
+int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins_in, int32_t* rowcnt,
                 const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
+    Bins bins = bins_in;
+    if (NUMERIC && bins.n_dense > 0) {
+        int phd = phase_begin(ctx, SPMM_PH_WINDOW_NUM_NARROW);
+        constexpr size_t dl = dense_lds_bytes(1024);
+        static_assert(dl <= 160 * 1024, "LDS budget of one CU");
+        auto kd = k_dense<1024>;
+        HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
+        hipLaunchKernelGGL(kd, dim3((unsigned)bins.n_dense), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr, A->indices,
+                           A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix, c_val, ctx->win_dbg >> 8);
+        phase_end(ctx, phd);
+        bins.list_w += bins.n_dense;
+        bins.n_w -= bins.n_dense;
+    }
     if (bins.n_w > 0) {
         int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
         if (ctx->win_cfg == 1) {
