@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                                                  const int64_t* __restrict__ prod, int32_t* __restrict__ rowcnt,
                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val,
-                                                 unsigned long long* __restrict__ stamps, int dbg, int min_len) {
+                                                 unsigned long long* __restrict__ stamps, int dbg, int adaptive) {
     static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
     static_assert(!NUMERIC || VALS <= WORDS, "column staging reuses the rank-prefix array");
     static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
@@ -296,7 +296,6 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
     const bool single_chunk = lenA <= THREADS;
-    if (lenA <= min_len) return;   // those rows belong to k_num (block-uniform exit)
 
     // base windows per LDS window: about U*THREADS products per window, at most the bitmap width
     int m = (WORDS * 32) >> shift;
@@ -306,20 +305,12 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         while (m > m_min && q * m > (long long)U * THREADS) m >>= 1;
     }
     // bitmap words of a window owned by one thread (contiguous): only the words the window covers
-    const int wpt = ((m << shift) >> 5) / THREADS;
+    const int wpt0 = ((m << shift) >> 5) / THREADS;
     int64_t out = 0;
     if (NUMERIC) out = c_ip[row] - c_ip[row_beg];
 
     // single-chunk rows keep their entry's table row and window bounds in registers and fetch
     // the bound of the NEXT window while the current one is processed
-    const int32_t* T = winptr;
-    int t_lo = 0, t_hi = 0;
-    if (single_chunk && tid < lenA) {
-        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
-        t_lo = T[0];
-        t_hi = T[m < nbase ? m : nbase];
-        if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
-    }
     for (int i = tid; i < WORDS; i += THREADS) bits[i] = 0u;
     if (NUMERIC)
         for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
@@ -327,6 +318,46 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     // stamp accumulators live in LDS so that the diagnostic build keeps the register allocation
     unsigned long long* st_lds = (unsigned long long*)(((uintptr_t)(tmp + 3 * (NW + 1)) + 7) & ~(uintptr_t)7);
     unsigned long long* st_arr = st_lds + 16;   // 5 x NW arrival times
+    // Adaptive windows (numeric): R-MAT-like rows put a quarter of their products into the first
+    // few table windows, so equal-width windows sized by the row average overflow the registers
+    // at the front and idle at the back.  cs[j] = sum over the row's entries of the table value at
+    // window j*gsz gives the products of any window range as a difference, and windows then grow
+    // granule by granule while they hold at most U*THREADS products.
+    uint32_t* cs = (uint32_t*)(st_arr + 5 * NW);
+    const int gsz = m_min;
+    const int nh = (nbase + gsz - 1) / gsz;
+    const int gmax = ((WORDS * 32) >> shift) / gsz;
+    if (NUMERIC && adaptive) {
+        for (int j = tid; j <= nh; j += THREADS) cs[j] = 0u;
+        __syncthreads();
+        for (int jb = 0; jb <= nh; jb += 64) {
+            const int j = jb + lane;
+            const int wj = j * gsz < nbase ? j * gsz : nbase;
+            uint32_t sum = 0;
+            if (j <= nh)
+                for (int e = wv; e < lenA; e += NW) sum += (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + wj];
+            if (j <= nh && sum) atomicAdd(&cs[j], sum);
+        }
+        __syncthreads();
+    }
+    // end of the window that starts at table window w0 (block-uniform)
+    auto window_end = [&](int w0) {
+        if (!(NUMERIC && adaptive)) return w0 + m < nbase ? w0 + m : nbase;
+        const int j0 = w0 / gsz;
+        const uint32_t base = cs[j0];
+        int j1 = j0 + 1;
+        while (j1 < nh && j1 - j0 < gmax && cs[j1 + 1] - base <= (uint32_t)(U * THREADS)) j1++;
+        return j1 * gsz < nbase ? j1 * gsz : nbase;
+    };
+    int w1_cur = window_end(0), w1_next = 0;
+    const int32_t* T = winptr;
+    int t_lo = 0, t_hi = 0;
+    if (single_chunk && tid < lenA) {
+        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
+        t_lo = T[0];
+        t_hi = T[w1_cur];
+        if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
+    }
     if (STAMP && tid == 0) {
         for (int i = 0; i < 15; i++) st_lds[i] = 0;
         st_lds[15] = win_clock();
@@ -343,8 +374,11 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         st_lds[slot] += mx_ - mn_;                                               \
     }
 
-    for (int w0 = 0; w0 < nbase; w0 += m) {
-        const int w1 = w0 + m < nbase ? w0 + m : nbase;
+    for (int w0 = 0; w0 < nbase; w0 = w1_cur, w1_cur = w1_next) {
+        const int w1 = w1_cur;
+        w1_next = w1 < nbase ? window_end(w1) : nbase;
+        // bitmap words of this window owned by one thread
+        const int wpt = (NUMERIC && adaptive) ? ((((w1 - w0 + gsz - 1) / gsz * gsz) << shift) >> 5) / THREADS : wpt0;
         const int wbase = w0 << shift;
         long long Tw = 0;
         int Tc = 0;
@@ -366,7 +400,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                     s = t_lo;
                     len = t_hi - t_lo;
                     t_lo = t_hi;
-                    if (w1 < nbase) t_hi = T[w1 + m < nbase ? w1 + m : nbase];
+                    if (w1 < nbase) t_hi = T[w1_next];
                 }
             } else {
                 const int e = c0 + tid;
@@ -1130,6 +1164,361 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tiers 2 and 3 of the barrier-free sweep, shared by the kernels below: lanes [0,E) of the wave
+// hold (s, rem) = start and count of the products of their entry that tier 1 left over; entries
+// with up to 128 of them go to 16-lane groups, four at a time, longer ones to the whole wave.
+// act(col, b) is called once per product; b_val is only read when WITH_VAL.
+template <bool WITH_VAL, typename F>
+__device__ __forceinline__ void sweep_tiers23(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
+                                              int rem, double a, int lane, F&& act) {
+    unsigned long long mask_c = __ballot(rem > 128);
+    unsigned long long mask_b = __ballot(rem > 0 && rem <= 128);
+    const int nb = __popcll(mask_b);
+    const int g = lane >> 4, sl = lane & 15;
+    for (int it = 0; it < nb; it += 4) {
+        int l4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            l4[q] = mask_b ? __ffsll(mask_b) - 1 : 0;
+            mask_b &= mask_b - 1;
+        }
+        const int src = g == 0 ? l4[0] : g == 1 ? l4[1] : g == 2 ? l4[2] : l4[3];
+        // every lane takes part in the shuffles: a masked-off source lane would read as 0
+        const int ss = __shfl(s, src, 64);
+        const int rsrc = __shfl(rem, src, 64);
+        const double aa = WITH_VAL ? __shfl(a, src, 64) : 0.0;
+        const int rr = it + g < nb ? rsrc : 0;
+        for (int i = sl; i < rr; i += 32) {
+            const bool v1 = i + 16 < rr;
+            const int c0 = b_ix[ss + i];
+            const int c1 = v1 ? b_ix[ss + i + 16] : -1;
+            double b0 = 0.0, b1 = 0.0;
+            if (WITH_VAL) {
+                b0 = b_val[ss + i];
+                if (v1) b1 = b_val[ss + i + 16];
+            }
+            act(c0, aa * b0);
+            if (v1) act(c1, aa * b1);
+        }
+    }
+    while (mask_c) {
+        const int src = __ffsll(mask_c) - 1;
+        mask_c &= mask_c - 1;
+        const int ss = __builtin_amdgcn_readlane(s, src);
+        const int rr = __builtin_amdgcn_readlane(rem, src);
+        const double aa = WITH_VAL ? readlane_f64(a, src) : 0.0;
+        for (int i = lane; i < rr; i += 256) {
+            int cq[4];
+            double bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool v = i + 64 * q < rr;
+                cq[q] = v ? b_ix[ss + i + 64 * q] : -1;
+                bq[q] = (WITH_VAL && v) ? b_val[ss + i + 64 * q] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i + 64 * q < rr) act(cq[q], aa * bq[q]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Numeric phase for window rows below the dense threshold: bitmap + rank prefix + compact fp64
+// accumulators per window as in k_win, but both sweeps (mark columns, add values) use the
+// barrier-free tiered mapping instead of a directory and cursors, and the bitmap has two buffers
+// so that clearing one never waits for the other.  Four barriers per window.
+template <int THREADS, int WORDS, int VALS>
+__global__ void __launch_bounds__(THREADS) k_cmp(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                 const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
+                                                 const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                 const int64_t* __restrict__ prod, const int64_t* __restrict__ c_ip,
+                                                 int32_t row_beg, int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    static_assert(WORDS % THREADS == 0, "geometry");
+    constexpr int WPT = WORDS / THREADS;
+    constexpr int NW = THREADS / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* bits_buf = (uint32_t*)smem;            // 2 x WORDS
+    uint32_t* pre = bits_buf + 2 * WORDS;            // WORDS
+    double* vals = (double*)(pre + WORDS);           // VALS
+    int32_t* tmp = (int32_t*)(vals + VALS);          // 2 x NW
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    const int lgE = lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
+    const int E = 1 << lgE, LA = 64 >> lgE;
+    const int npass = (lenA + E * NW - 1) / (E * NW);
+    const bool cached = npass == 1;
+    const int el = lane & (E - 1), pi = lane >> lgE;
+
+    // table windows per LDS window: about VALS products, at most the bitmap width, and every
+    // thread owns at least one bitmap word
+    int m = (WORDS * 32) >> shift;
+    {
+        const int m_min = (THREADS * 32) >> shift > 1 ? (THREADS * 32) >> shift : 1;
+        const long long q = prod[row] / nbase;
+        while (m > m_min && q * m > (long long)VALS) m >>= 1;
+    }
+    const int wpt = ((m << shift) >> 5) / THREADS;
+    int64_t out = c_ip[row] - c_ip[row_beg];
+
+    const int32_t* Tp = winptr;
+    double av = 0.0;
+    int t_cur = 0, t_nxt = 0;
+    bool have = false;
+    if (cached) {
+        const int e = el * NW + wv;
+        have = e < lenA;
+        if (have) {
+            Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+            av = a_val[a0 + e];
+            t_cur = Tp[0];
+            t_nxt = Tp[m < nbase ? m : nbase];
+        }
+    }
+    for (int i = tid; i < 2 * WORDS; i += THREADS) bits_buf[i] = 0u;
+    for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
+    __syncthreads();
+
+    int flip = 0;
+    for (int w0 = 0; w0 < nbase; w0 += m) {
+        const int w1 = w0 + m < nbase ? w0 + m : nbase;
+        const int wbase = w0 << shift;
+        flip ^= 1;
+        uint32_t* bits = bits_buf + flip * WORDS;
+        int s_c = 0, len_c = 0;
+        if (cached) {
+            s_c = t_cur;
+            len_c = t_nxt - t_cur;
+            t_cur = t_nxt;
+            if (have && w1 < nbase) t_nxt = Tp[w1 + m < nbase ? w1 + m : nbase];
+        }
+        // ---- sweep 1: one bit per touched column ------------------------------
+        for (int c = 0; c < npass; c++) {
+            int s = s_c, len = len_c;
+            if (!cached) {
+                const int e = ((c << lgE) + el) * NW + wv;
+                len = 0;
+                if (e < lenA) {
+                    const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                    s = Tq[w0];
+                    len = Tq[w1] - s;
+                }
+            }
+            const bool v0 = pi < len, v1 = pi + LA < len;
+            const int q0 = v0 ? b_ix[s + pi] - wbase : 0;
+            const int q1 = v1 ? b_ix[s + pi + LA] - wbase : 0;
+            if (v0) atomicOr(&bits[q0 >> 5], 1u << (q0 & 31));
+            if (v1) atomicOr(&bits[q1 >> 5], 1u << (q1 & 31));
+            sweep_tiers23<false>(b_ix, b_val, s + 2 * LA, lane < E ? len - 2 * LA : 0, 0.0, lane, [&](int col, double) {
+                const int lc = col - wbase;
+                atomicOr(&bits[lc >> 5], 1u << (lc & 31));
+            });
+        }
+        __syncthreads();
+        // ---- rank prefix ---------------------------------------------------------
+        uint32_t myw[WPT];
+        int cntw, rbase;
+        {
+            int sum = 0;
+#pragma unroll
+            for (int j = 0; j < WPT; j++) {
+                myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
+                sum += __popc(myw[j]);
+            }
+            rbase = block_exclusive_scan_1b<THREADS, int32_t>(sum, tmp + flip * NW, &cntw);
+            int r = rbase;
+#pragma unroll
+            for (int j = 0; j < WPT; j++)
+                if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
+        }
+        if (cntw == 0) continue;   // block-uniform; nothing was marked, nothing to clear
+        for (int r0 = 0; r0 < cntw; r0 += VALS) {
+            const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
+            __syncthreads();   // rank prefix complete / accumulators of the previous pass written out
+            // ---- sweep 2: add the products whose rank falls into [r0, r0 + nsub) ----------
+            auto add = [&](int col, double v) {
+                const int lc = col - wbase;
+                const int r = (int)pre[lc >> 5] + __popc(bits[lc >> 5] & ((1u << (lc & 31)) - 1u)) - r0;
+                if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], v);
+            };
+            for (int c = 0; c < npass; c++) {
+                int s = s_c, len = len_c;
+                double a = av;
+                if (!cached) {
+                    const int e = ((c << lgE) + el) * NW + wv;
+                    len = 0;
+                    if (e < lenA) {
+                        const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                        s = Tq[w0];
+                        len = Tq[w1] - s;
+                        a = a_val[a0 + e];
+                    }
+                }
+                const bool v0 = pi < len, v1 = pi + LA < len;
+                const int q0 = v0 ? b_ix[s + pi] : 0;
+                const double x0 = v0 ? b_val[s + pi] : 0.0;
+                const int q1 = v1 ? b_ix[s + pi + LA] : 0;
+                const double x1 = v1 ? b_val[s + pi + LA] : 0.0;
+                if (v0) add(q0, a * x0);
+                if (v1) add(q1, a * x1);
+                sweep_tiers23<true>(b_ix, b_val, s + 2 * LA, lane < E ? len - 2 * LA : 0, a, lane, add);
+            }
+            __syncthreads();
+            // ---- write out ranks [r0, r0 + nsub) -----------------------------------
+            for (int r = tid; r < nsub; r += THREADS) {
+                c_val[out + r0 + r] = vals[r];
+                vals[r] = 0.0;
+            }
+            int r = rbase;
+#pragma unroll
+            for (int j = 0; j < WPT; j++) {
+                uint32_t bw = myw[j];
+                const int cb = wbase + (tid * wpt + j) * 32;
+                while (bw) {
+                    const int b = __ffs(bw) - 1;
+                    bw &= bw - 1u;
+                    if (r >= r0 && r < r0 + nsub) c_ix[out + r] = cb + b;
+                    r++;
+                }
+            }
+        }
+        // the other buffer serves the next window; this one is cleared for the one after
+#pragma unroll
+        for (int j = 0; j < WPT; j++)
+            if (j < wpt && myw[j]) bits[tid * wpt + j] = 0u;
+        out += cntw;
+    }
+}
+
+template <int THREADS, int WORDS, int VALS>
+constexpr size_t cmp_lds_bytes() { return (size_t)WORDS * 12 + (size_t)VALS * 8 + (size_t)(THREADS / 64) * 8; }
+
+// ---------------------------------------------------------------------------
+// Symbolic phase for window rows with the same barrier-free tiered sweep: the bitmap covers
+// SYM_COLS columns per pass (a whole row of C for matrices up to that width), a product costs one
+// 4-byte load and one ds_or_b32, and the row count is the popcount of the bitmap.
+constexpr int SYM_COLS = 1 << 20;
+
+__device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
+    const unsigned lc = (unsigned)(col - cbase);
+    atomicOr(&bits[lc >> 5], 1u << (lc & 31));
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                  const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
+                                                  const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                  int32_t* __restrict__ rowcnt) {
+    constexpr int NW = THREADS / 64;
+    constexpr int WORDS = SYM_COLS / 32;
+    constexpr int WPT = WORDS / THREADS;
+    static_assert(WPT % 4 == 0, "the count pass reads 16 bytes at a time");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* bits = (uint32_t*)smem;
+    int32_t* tmp = (int32_t*)(bits + WORDS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    const int lgE = lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
+    const int E = 1 << lgE, LA = 64 >> lgE;
+    const int npass = (lenA + E * NW - 1) / (E * NW);
+    const int el = lane & (E - 1), pi = lane >> lgE;
+    const int mwin = SYM_COLS >> shift;   // table windows per bitmap pass
+
+    for (int i = tid; i < WORDS / 4; i += THREADS) ((uint4*)bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) tmp[0] = 0;
+    __syncthreads();
+
+    for (int w0 = 0; w0 < nbase; w0 += mwin) {
+        const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
+        const int cbase = w0 << shift;
+        for (int c = 0; c < npass; c++) {
+            const int e = ((c << lgE) + el) * NW + wv;
+            int s = 0, len = 0;
+            if (e < lenA) {
+                const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                s = Tq[w0];
+                len = Tq[w1] - s;
+            }
+            // tier 1: products pi and pi+LA of the lane's own entry
+            {
+                const bool v0 = pi < len, v1 = pi + LA < len;
+                const int q0 = v0 ? b_ix[s + pi] : 0;
+                const int q1 = v1 ? b_ix[s + pi + LA] : 0;
+                if (v0) sym_mark(bits, q0, cbase);
+                if (v1) sym_mark(bits, q1, cbase);
+            }
+            const int rem = lane < E ? len - 2 * LA : 0;
+            unsigned long long mask_c = __ballot(rem > 128);
+            unsigned long long mask_b = __ballot(rem > 0 && rem <= 128);
+            // tier 2: 16 lanes per entry, four entries at a time
+            const int nb = __popcll(mask_b);
+            const int g = lane >> 4, sl = lane & 15;
+            for (int it = 0; it < nb; it += 4) {
+                int l4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    l4[q] = mask_b ? __ffsll(mask_b) - 1 : 0;
+                    mask_b &= mask_b - 1;
+                }
+                const int src = g == 0 ? l4[0] : g == 1 ? l4[1] : g == 2 ? l4[2] : l4[3];
+                // every lane takes part in the shuffles: a masked-off source lane would read as 0
+                const int ss = __shfl(s, src, 64) + 2 * LA;
+                const int rsrc = __shfl(rem, src, 64);
+                const int rr = it + g < nb ? rsrc : 0;
+                for (int i = sl; i < rr; i += 64) {
+                    int cq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cq[q] = i + 16 * q < rr ? b_ix[ss + i + 16 * q] : -1;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (i + 16 * q < rr) sym_mark(bits, cq[q], cbase);
+                }
+            }
+            // tier 3: the whole wave on one entry
+            while (mask_c) {
+                const int src = __ffsll(mask_c) - 1;
+                mask_c &= mask_c - 1;
+                const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
+                const int rr = __builtin_amdgcn_readlane(rem, src);
+                for (int i = lane; i < rr; i += 512) {
+                    int cq[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) cq[q] = i + 64 * q < rr ? b_ix[ss + i + 64 * q] : -1;
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (i + 64 * q < rr) sym_mark(bits, cq[q], cbase);
+                }
+            }
+        }
+        __syncthreads();
+        // count and clear: thread t owns words [WPT*t, WPT*(t+1))
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < WPT / 4; j++) {
+            const uint4 x = ((const uint4*)bits)[tid * (WPT / 4) + j];
+            const int cj = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+            if (cj) ((uint4*)bits)[tid * (WPT / 4) + j] = make_uint4(0u, 0u, 0u, 0u);
+            cnt += cj;
+        }
+        cnt = wave_reduce_sum(cnt);
+        if (lane == 0 && cnt) atomicAdd(&tmp[0], cnt);
+        __syncthreads();
+    }
+    if (tid == 0) rowcnt[row] = tmp[0];
+}
+
+constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16; }
+
 constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * 8; }
 
 template <int THREADS, int WORDS, int VALS>
@@ -1140,7 +1529,8 @@ constexpr size_t num_lds_bytes() {
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
     return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
-           (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8;
+           (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
+           (NUMERIC ? (size_t)(1024 + 2) * 4 : 0);   // adaptive-window sums: at most 1024 table windows
 }
 
 // ---------------------------------------------------------------------------
@@ -1282,6 +1672,24 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
+    if (NUMERIC && ctx->cmp_cfg > 0 && ctx->win_cfg == 0 && !ctx->win_stamps && !ctx->win_dbg) {
+        if (ctx->cmp_cfg == 2 && bins.shift <= 16) {   // two 512-thread workgroups per CU
+            constexpr size_t cl = cmp_lds_bytes<512, 2048, 4096>();
+            static_assert(2 * cl <= 160 * 1024, "two workgroups per CU");
+            auto kc = k_cmp<512, 2048, 4096>;
+            HIPCHK(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
+            hipLaunchKernelGGL(kc, dim3((unsigned)bins.n_w), dim3(512), cl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
+                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
+        } else {
+            constexpr size_t cl = cmp_lds_bytes<1024, 4096, 8192>();
+            static_assert(cl <= 160 * 1024, "LDS budget of one CU");
+            auto kc = k_cmp<1024, 4096, 8192>;
+            HIPCHK(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
+            hipLaunchKernelGGL(kc, dim3((unsigned)bins.n_w), dim3(1024), cl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
+                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
+        }
+        return SPMM_OK;
+    }
     const bool lean = NUMERIC && ctx->num_cfg >= 0 && ctx->win_cfg == 0 && !ctx->win_stamps && !ctx->win_dbg;
     auto kern = ctx->win_stamps ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
@@ -1290,7 +1698,7 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
                        A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
                        c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
-                       -1);
+                       (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0);
     if (lean) {
         int phw = phase_begin(ctx, SPMM_PH_WINDOW_NUM_NARROW);
         if (ctx->num_cfg == 1) {          // two 512-thread workgroups per CU
@@ -1335,6 +1743,17 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;
         bins.n_w -= bins.n_dense;
+    }
+    if (!NUMERIC && bins.n_w > 0 && ctx->sym_cfg == 0 && bins.shift <= 20) {
+        int phs = phase_begin(ctx, SPMM_PH_WINDOW_SYM);
+        constexpr size_t sl = symd_lds_bytes();
+        static_assert(sl <= 160 * 1024, "LDS budget of one CU");
+        auto ks = k_symd<1024>;
+        HIPCHK(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+        hipLaunchKernelGGL(ks, dim3((unsigned)bins.n_w), dim3(1024), sl, ctx->stream, bins.list_w, A->indptr, A->indices,
+                           B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt);
+        phase_end(ctx, phs);
+        bins.n_w = 0;
     }
     if (bins.n_w > 0) {
         int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
