@@ -183,7 +183,7 @@ def main():
     ph = {name: ctx.phase_ms(pid) for name, pid in
           [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
            ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN),
-           ("window_num_narrow", 13)]}
+           ("dense_num", capi.PH_DENSE_NUM)]}
     ctx.profile(False)
     stamps = None
     if os.environ.get("SPMM_WIN_STAMPS") == "1":
@@ -211,21 +211,32 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: numeric over the window rows (rank 0's share) -------
+    # ---- roofline of the dominant kernel (rank 0's share) ------------------------------
+    # Numeric runs two kernels over the rows above the expand-sort-compress limit: k_dense over the
+    # rows with at least dense_min products, k_win over the rest.  The one with more time per step
+    # is reported, with the algorithmic bytes of its own rows:
+    #   12 B per product (column id + value of B) + 20 B per entry of A (column id, value, two
+    #   table bounds) + 12 B per row (row pointers of A and C) + 12 B per entry of C written.
     esc_s, esc_l = capi.bin_limits()
+    shift, nbase, dense_min = ctx.plan_info(n)
     pl = prod[r_lo:r_hi]
-    wmask = pl > esc_l
     lens_l = (indptr[r_lo + 1:r_hi + 1] - indptr[r_lo:r_hi]).to(torch.int64)
     rowc = c_ip[1:] - c_ip[:-1]
+    masks = {"k_dense": pl >= dense_min, "k_win<numeric>": (pl > esc_l) & (pl < dense_min)}
+    times = {"k_dense": ph["dense_num"], "k_win<numeric>": ph["window_num"]}
+    kname = max(times, key=lambda k: times[k][0])
+    wmask = masks[kname]
     P_w, nnzA_w, rows_w, nnzC_w = int(pl[wmask].sum()), int(lens_l[wmask].sum()), int(wmask.sum()), int(rowc[wmask].sum())
     bytes_w = 12 * P_w + 20 * nnzA_w + 12 * (rows_w + 1) + 12 * nnzC_w
-    t_w_ms = ph["window_num"][0] / args.steps
+    t_w_ms = times[kname][0] / args.steps
     achieved = bytes_w / (t_w_ms * 1e-3) / 1e9 if t_w_ms > 0 else 0.0
-    roofline = dict(bound="hbm", kernel="k_window<numeric>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     algorithmic_bytes_per_step=bytes_w, kernel_ms_per_step=round(t_w_ms, 3),
-                    launches_per_step=ph["window_num"][1] // max(args.steps, 1),
-                    numeric_gflops=round(2.0 * P_w / (t_w_ms * 1e-3) / 1e9, 1) if t_w_ms > 0 else None)
+                    launches_per_step=times[kname][1] // max(args.steps, 1),
+                    rows=rows_w, products=P_w, nnz_c=nnzC_w,
+                    numeric_gflops=round(2.0 * P_w / (t_w_ms * 1e-3) / 1e9, 1) if t_w_ms > 0 else None,
+                    table=dict(shift=shift, windows=nbase, dense_min_products=dense_min))
 
     # ---- CPU baseline: the oracle's serial Gustavson on the first rows of the same matrix -----
     cpu = None

@@ -77,7 +77,7 @@ enum {
     SPMM_PH_PACK = 10,       /* block row gather + 8-row interleave (serial_newblock_clock.cpp:336-399) */
     SPMM_PH_RENUMBER = 11,   /* first-touch renumbering (serial_newblock_clock.cpp:187) */
     SPMM_PH_WBSEQ = 12,      /* write-back sequence (wbsort.h) */
-    SPMM_PH_WINDOW_NUM_NARROW = 13, /* part of SPMM_PH_WINDOW_NUM: rows with at most 1024 entries in A */
+    SPMM_PH_DENSE_NUM = 13,         /* numeric over the product-heaviest rows (dense fp64 accumulators) */
     SPMM_PH_COUNT = 32
 };
 int spmm_ctx_profile(spmm_ctx* ctx, int enable);
@@ -86,6 +86,11 @@ int spmm_ctx_phase_ms(spmm_ctx* ctx, int phase, double* total_ms, int* launches)
  * are handled by the 64-lane / 256-thread expand-sort-compress kernels, heavier rows by the
  * window kernel. */
 void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
+/* Plan parameters the context would use for a right-hand matrix with b_ncol columns: the window
+ * table has *nbase windows of 2^*shift columns per row of B, and rows of A with at least
+ * *dense_min_products intermediate products take the dense-accumulator numeric kernel (INT64_MAX
+ * when that kernel is switched off).  Diagnostic, no counterpart in the reference. */
+int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shift, int32_t* nbase, int64_t* dense_min_products);
 
 /* ---- CSR build: replaces the in-memory part of csr_matrix(),
  *      serial_newblock_clock.cpp:78-112 (row histogram, exclusive scan, scatter that keeps

@@ -17,6 +17,7 @@ I32, I64, F64 = np.int32, np.int64, np.float64
 
 
 PH_BINS, PH_WINDOW_SYM, PH_ESC_SYM, PH_WINDOW_NUM, PH_ESC_NUM, PH_SCAN, PH_CSR_BUILD = range(7)
+PH_DENSE_NUM = 13
 
 
 def bin_limits():
@@ -131,6 +132,12 @@ class Context:
         out = np.zeros(32, np.uint64)
         _chk(lib().spmm_debug_stamps(self._h, _p(out), C.c_int(1 if reset else 0)))
         return out
+
+    def plan_info(self, b_ncol):
+        """(shift, nbase, dense_min_products) the context uses for a right-hand matrix of b_ncol columns."""
+        sh, nb, dm = C.c_int32(), C.c_int32(), C.c_int64()
+        _chk(lib().spmm_spgemm_plan_info(self._h, C.c_int32(int(b_ncol)), C.byref(sh), C.byref(nb), C.byref(dm)))
+        return int(sh.value), int(nb.value), int(dm.value)
 
     def last_kernel_ms(self):
         return float(lib().spmm_last_kernel_ms(self._h))

@@ -62,12 +62,9 @@ struct spmm_ctx {
     plan_cache plan;
     bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int adaptive = 1;       // numeric k_win: window widths follow the row's product distribution
-    int cmp_cfg = 0;        // numeric kernel below the dense threshold: 0 = k_win, 1 = k_cmp 1024 threads, 2 = k_cmp 2 x 512
     int sym_cfg = 0;        // symbolic window kernel: 0 = k_symd (tiered sweep), 1 = k_win
-    int dense_min = 2048;   // rows with at least this many products per table window use k_dense; 0 = off
-    int num_cfg = -1;  // numeric window kernel: -1 = k_win; k_num with 0 = 1024 threads, 1 = 2 x 512, 2 = 4 x 256 per CU
+    long long dense_min = 1 << 18;   // rows with at least this many intermediate products use k_dense; 0 = off
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
-    int win_cfg = 0;   // window-kernel geometry: 0 = 1024 threads, 1 = 512 threads (2 workgroups per CU)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse
     int device = 0;

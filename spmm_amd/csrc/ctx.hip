@@ -39,11 +39,8 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
         return SPMM_E_HIP;
     }
     c->own_stream = true;
-    if (const char* e = getenv("SPMM_WIN_CFG")) c->win_cfg = atoi(e);
-    if (const char* e = getenv("SPMM_NUM_CFG")) c->num_cfg = atoi(e);
-    if (const char* e = getenv("SPMM_DENSE_MIN")) c->dense_min = atoi(e);
+    if (const char* e = getenv("SPMM_DENSE_MIN")) c->dense_min = atoll(e);
     if (const char* e = getenv("SPMM_SYM_CFG")) c->sym_cfg = atoi(e);
-    if (const char* e = getenv("SPMM_CMP_CFG")) c->cmp_cfg = atoi(e);
     if (const char* e = getenv("SPMM_ADAPTIVE")) c->adaptive = atoi(e);
     if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);
     if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e) != 0;

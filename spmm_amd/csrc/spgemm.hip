@@ -666,285 +666,6 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
 }
 
 // ---------------------------------------------------------------------------
-// Numeric phase for window rows: the same algorithm as k_win<NUMERIC>, kept small so that several
-// workgroups fit a CU and overlap each other's memory and barrier waits: no branches inside the
-// per-product loops (lanes past the end of a wave's slice repeat its last product with a zero bit
-// mask / a zero addend), nothing kept in registers across phases except the U products of a
-// register-resident window.  Rows with at most THREADS entries in A use one directory per window
-// (two buffers, alternating, entry bounds prefetched one window ahead); wider rows rebuild the
-// directory per chunk of THREADS entries and take the two-sweep form.
-template <int THREADS, int WORDS, int VALS, int U, int MINW>
-__global__ void __launch_bounds__(THREADS, MINW) k_num(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
-                                                       const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                                       const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
-                                                       const int32_t* __restrict__ winptr, int nbase, int shift,
-                                                       const int64_t* __restrict__ prod, const int64_t* __restrict__ c_ip,
-                                                       int32_t row_beg, int32_t* __restrict__ c_ix,
-                                                       double* __restrict__ c_val) {
-    static_assert(WORDS % THREADS == 0 && VALS <= WORDS && U * THREADS <= VALS, "geometry");
-    constexpr int WPT = WORDS / THREADS;
-    constexpr int NW = THREADS / 64;
-    constexpr int CAP = U * THREADS;
-    constexpr int UG = 4;
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* bits = (uint32_t*)smem;
-    uint32_t* pre = bits + WORDS;
-    double* vals = (double*)(smem + (size_t)WORDS * 8);
-    double* dir_av = vals + VALS;
-    int2* dir_buf = (int2*)(dir_av + THREADS);           // 2 x (THREADS + 1)
-    int32_t* tmp_a = (int32_t*)(dir_buf + 2 * (THREADS + 1));
-    int32_t* tmp_b = tmp_a + NW;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row = list[blockIdx.x];
-    const int a0 = a_ip[row];
-    const int lenA = a_ip[row + 1] - a0;
-    const bool single = lenA <= THREADS;
-    const int64_t tstride = (int64_t)nbase + 1;
-
-    int m = (WORDS * 32) >> shift;
-    {
-        const int m_min = (THREADS * 32) >> shift > 1 ? (THREADS * 32) >> shift : 1;   // every thread owns at least one word
-        const long long q = prod[row] / nbase;
-        while (m > m_min && q * m > (long long)CAP) m >>= 1;
-    }
-    const int wpt = ((m << shift) >> 5) / THREADS;
-    int64_t out = c_ip[row] - c_ip[row_beg];
-
-    const int32_t* T = winptr;
-    int t_lo = 0, t_hi = 0;
-    if (single && tid < lenA) {
-        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
-        t_lo = T[0];
-        t_hi = T[m < nbase ? m : nbase];
-        dir_av[tid] = a_val[a0 + tid];
-    }
-    for (int i = tid; i < WORDS; i += THREADS) bits[i] = 0u;
-    for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
-    int flip = 0;
-
-    for (int w0 = 0; w0 < nbase; w0 += m) {
-        const int w1 = w0 + m < nbase ? w0 + m : nbase;
-        const int wbase = w0 << shift;
-        flip ^= 1;
-        int2* dir = dir_buf + (single ? flip * (THREADS + 1) : 0);
-        long long Tw = 0;
-        int Tc = 0, p_lo = 0, p_hi = 0;
-        bool one = false;
-        int cc[U];
-        double pv[U];
-        // ---- bit sweep -------------------------------------------------------
-        for (int c0 = 0; c0 < lenA; c0 += THREADS) {
-            int s = 0, len = 0;
-            if (single) {
-                s = t_lo;
-                len = t_hi - t_lo;
-                t_lo = t_hi;
-                if (tid < lenA && w1 < nbase) t_hi = T[w1 + m < nbase ? w1 + m : nbase];
-            } else {
-                __syncthreads();   // readers of the previous chunk's directory are done
-                const int e = c0 + tid;
-                if (e < lenA) {
-                    const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
-                    s = Tp[w0];
-                    len = Tp[w1] - s;
-                    dir_av[tid] = a_val[a0 + e];
-                }
-            }
-            const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
-            dir[tid] = make_int2(off, s);
-            if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
-            __syncthreads();
-            Tw += Tc;
-            if (Tc == 0) continue;
-            const int per = ((Tc + NW - 1) / NW + 63) & ~63;
-            p_lo = wv * per;
-            p_hi = p_lo + per < Tc ? p_lo + per : Tc;
-            one = single && Tc <= CAP;          // block-uniform: the window stays in registers
-            if (p_lo >= p_hi) continue;         // wave-uniform
-            WinCursor<THREADS> cur;
-            cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
-            double av = dir_av[cur.e];
-            if (one) {
-                int pos[U];
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const int p = p_lo + j * 64 + lane;
-                    const bool valid = p < p_hi;
-                    const int pc = valid ? p : p_hi - 1;
-                    if (cur.seek(dir, pc)) av = dir_av[cur.e];
-                    pos[j] = cur.start + (pc - cur.off);
-                    pv[j] = av;
-                }
-                double bv[U];
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    cc[j] = b_ix[pos[j]];
-                    bv[j] = b_val[pos[j]];
-                }
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const bool valid = p_lo + j * 64 + lane < p_hi;
-                    atomicOr(&bits[(cc[j] - wbase) >> 5], valid ? 1u << ((cc[j] - wbase) & 31) : 0u);
-                    pv[j] = valid ? pv[j] * bv[j] : 0.0;
-                }
-            } else {
-                for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
-                    int pos[UG];
-#pragma unroll
-                    for (int j = 0; j < UG; j++) {
-                        const int p = pb + j * 64 + lane;
-                        const int pc = p < p_hi ? p : p_hi - 1;
-                        cur.seek(dir, pc);
-                        pos[j] = cur.start + (pc - cur.off);
-                    }
-                    int c[UG];
-#pragma unroll
-                    for (int j = 0; j < UG; j++) c[j] = b_ix[pos[j]];
-#pragma unroll
-                    for (int j = 0; j < UG; j++)   // a repeated product sets a bit that is set anyway
-                        atomicOr(&bits[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
-                }
-            }
-        }
-        if (Tw == 0) continue;
-        __syncthreads();
-        // ---- rank prefix -------------------------------------------------------
-        int cntw;
-        {
-            uint32_t myw[WPT];
-            int sum = 0;
-#pragma unroll
-            for (int j = 0; j < WPT; j++) {
-                myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
-                sum += __popc(myw[j]);
-            }
-            int r = block_exclusive_scan_1b<THREADS, int32_t>(sum, tmp_b, &cntw);
-#pragma unroll
-            for (int j = 0; j < WPT; j++)
-                if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
-        }
-        const bool staged = cntw <= VALS;
-        for (int r0 = 0; r0 < cntw; r0 += VALS) {
-            const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
-            // ---- value phase ---------------------------------------------------
-            if (one) {
-                __syncthreads();   // rank prefix complete
-                if (p_lo < p_hi) {
-                    // all rank look-ups first: LDS reads cannot move across the atomics
-#pragma unroll
-                    for (int j = 0; j < U; j++) {
-                        const int cj = cc[j] - wbase;
-                        cc[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u));
-                    }
-#pragma unroll
-                    for (int j = 0; j < U; j++) atomicAdd(&vals[cc[j]], pv[j]);
-                }
-            } else {
-                for (int c0 = 0; c0 < lenA; c0 += THREADS) {
-                    __syncthreads();   // rank prefix complete / previous output done / directory readers done
-                    if (!single) {
-                        const int e = c0 + tid;
-                        int s = 0, len = 0;
-                        if (e < lenA) {
-                            const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
-                            s = Tp[w0];
-                            len = Tp[w1] - s;
-                            dir_av[tid] = a_val[a0 + e];
-                        }
-                        const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
-                        dir[tid] = make_int2(off, s);
-                        if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
-                        __syncthreads();
-                        if (Tc == 0) continue;
-                        const int per = ((Tc + NW - 1) / NW + 63) & ~63;
-                        p_lo = wv * per;
-                        p_hi = p_lo + per < Tc ? p_lo + per : Tc;
-                    }
-                    if (p_lo >= p_hi) continue;
-                    WinCursor<THREADS> cur;
-                    cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
-                    double av = dir_av[cur.e];
-                    for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
-                        int pos[UG];
-                        double pa[UG];
-#pragma unroll
-                        for (int j = 0; j < UG; j++) {
-                            const int p = pb + j * 64 + lane;
-                            const int pc = p < p_hi ? p : p_hi - 1;
-                            if (cur.seek(dir, pc)) av = dir_av[cur.e];
-                            pos[j] = cur.start + (pc - cur.off);
-                            pa[j] = av;
-                        }
-                        int c[UG];
-                        double bv[UG];
-#pragma unroll
-                        for (int j = 0; j < UG; j++) {
-                            c[j] = b_ix[pos[j]];
-                            bv[j] = b_val[pos[j]];
-                        }
-#pragma unroll
-                        for (int j = 0; j < UG; j++) {
-                            const int cj = c[j] - wbase;
-                            c[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u)) - r0;
-                        }
-#pragma unroll
-                        for (int j = 0; j < UG; j++) {
-                            const bool valid = pb + j * 64 + lane < p_hi;
-                            if (valid && (unsigned)c[j] < (unsigned)nsub) atomicAdd(&vals[c[j]], pa[j] * bv[j]);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- write out ranks [r0, r0+nsub) ------------------------------------
-            for (int r = tid; r < nsub; r += THREADS) {
-                c_val[out + r0 + r] = vals[r];
-                vals[r] = 0.0;
-            }
-            if (staged) {
-                // column ids through LDS (the rank prefix is no longer needed) for coalesced stores
-                int32_t* stage = (int32_t*)pre;
-                int r = (int)pre[tid * wpt];
-                uint32_t myw[WPT];
-#pragma unroll
-                for (int j = 0; j < WPT; j++) myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
-                __syncthreads();   // every thread has read its rank base before the array is reused
-#pragma unroll
-                for (int j = 0; j < WPT; j++) {
-                    uint32_t bw = myw[j];
-                    const int cbase = wbase + (tid * wpt + j) * 32;
-                    while (bw) {
-                        stage[r++] = cbase + (__ffs(bw) - 1);
-                        bw &= bw - 1u;
-                    }
-                }
-                __syncthreads();
-                for (int r2 = tid; r2 < nsub; r2 += THREADS) c_ix[out + r2] = stage[r2];
-            } else {
-                int r = (int)pre[tid * wpt];
-#pragma unroll
-                for (int j = 0; j < WPT; j++) {
-                    uint32_t bw = j < wpt ? bits[tid * wpt + j] : 0u;
-                    const int cbase = wbase + (tid * wpt + j) * 32;
-                    while (bw) {
-                        const int b = __ffs(bw) - 1;
-                        bw &= bw - 1u;
-                        if (r >= r0 && r < r0 + nsub) c_ix[out + r] = cbase + b;
-                        r++;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WPT; j++)
-            if (j < wpt) bits[tid * wpt + j] = 0u;
-        out += cntw;
-        if (!single) __syncthreads();   // the cleared bitmap and the directory are free for the next window
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Numeric phase for the product-heaviest rows: dense accumulators.  A window is DENSE_COLS
 // columns of C held as fp64 sums in LDS plus one flag byte per column; every product is read
 // once and added with ds_add_f64, and the output pass walks the flags in column order, so the
@@ -1131,11 +852,12 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             // sums leave LDS (and the slots are cleared) before the scan barrier, so the next sweep
             // can start right after it
             double vr[16];
-            if (m16) {
-                ((uint4*)flags)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (m16) ((uint4*)flags)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            {
                 unsigned mm = m16;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
+                    if (__ballot(mm != 0u) == 0ull) break;   // wave-uniform: sparse windows leave after a few steps
                     if (mm) {
                         const int lc = tid * 16 + __ffs(mm) - 1;
                         mm &= mm - 1u;
@@ -1147,10 +869,11 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             flip ^= NW;
             int total;
             int r = block_exclusive_scan_1b<THREADS, int32_t>(__popc(m16), tmp + flip, &total);
-            if (m16) {
+            {
                 unsigned mm = m16;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
+                    if (__ballot(mm != 0u) == 0ull) break;
                     if (mm) {
                         const int lc = tid * 16 + __ffs(mm) - 1;
                         mm &= mm - 1u;
@@ -1163,241 +886,6 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
         }
     }
 }
-
-// ---------------------------------------------------------------------------
-// Tiers 2 and 3 of the barrier-free sweep, shared by the kernels below: lanes [0,E) of the wave
-// hold (s, rem) = start and count of the products of their entry that tier 1 left over; entries
-// with up to 128 of them go to 16-lane groups, four at a time, longer ones to the whole wave.
-// act(col, b) is called once per product; b_val is only read when WITH_VAL.
-template <bool WITH_VAL, typename F>
-__device__ __forceinline__ void sweep_tiers23(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
-                                              int rem, double a, int lane, F&& act) {
-    unsigned long long mask_c = __ballot(rem > 128);
-    unsigned long long mask_b = __ballot(rem > 0 && rem <= 128);
-    const int nb = __popcll(mask_b);
-    const int g = lane >> 4, sl = lane & 15;
-    for (int it = 0; it < nb; it += 4) {
-        int l4[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            l4[q] = mask_b ? __ffsll(mask_b) - 1 : 0;
-            mask_b &= mask_b - 1;
-        }
-        const int src = g == 0 ? l4[0] : g == 1 ? l4[1] : g == 2 ? l4[2] : l4[3];
-        // every lane takes part in the shuffles: a masked-off source lane would read as 0
-        const int ss = __shfl(s, src, 64);
-        const int rsrc = __shfl(rem, src, 64);
-        const double aa = WITH_VAL ? __shfl(a, src, 64) : 0.0;
-        const int rr = it + g < nb ? rsrc : 0;
-        for (int i = sl; i < rr; i += 32) {
-            const bool v1 = i + 16 < rr;
-            const int c0 = b_ix[ss + i];
-            const int c1 = v1 ? b_ix[ss + i + 16] : -1;
-            double b0 = 0.0, b1 = 0.0;
-            if (WITH_VAL) {
-                b0 = b_val[ss + i];
-                if (v1) b1 = b_val[ss + i + 16];
-            }
-            act(c0, aa * b0);
-            if (v1) act(c1, aa * b1);
-        }
-    }
-    while (mask_c) {
-        const int src = __ffsll(mask_c) - 1;
-        mask_c &= mask_c - 1;
-        const int ss = __builtin_amdgcn_readlane(s, src);
-        const int rr = __builtin_amdgcn_readlane(rem, src);
-        const double aa = WITH_VAL ? readlane_f64(a, src) : 0.0;
-        for (int i = lane; i < rr; i += 256) {
-            int cq[4];
-            double bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const bool v = i + 64 * q < rr;
-                cq[q] = v ? b_ix[ss + i + 64 * q] : -1;
-                bq[q] = (WITH_VAL && v) ? b_val[ss + i + 64 * q] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (i + 64 * q < rr) act(cq[q], aa * bq[q]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Numeric phase for window rows below the dense threshold: bitmap + rank prefix + compact fp64
-// accumulators per window as in k_win, but both sweeps (mark columns, add values) use the
-// barrier-free tiered mapping instead of a directory and cursors, and the bitmap has two buffers
-// so that clearing one never waits for the other.  Four barriers per window.
-template <int THREADS, int WORDS, int VALS>
-__global__ void __launch_bounds__(THREADS) k_cmp(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
-                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                                 const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
-                                                 const int32_t* __restrict__ winptr, int nbase, int shift,
-                                                 const int64_t* __restrict__ prod, const int64_t* __restrict__ c_ip,
-                                                 int32_t row_beg, int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
-    static_assert(WORDS % THREADS == 0, "geometry");
-    constexpr int WPT = WORDS / THREADS;
-    constexpr int NW = THREADS / 64;
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* bits_buf = (uint32_t*)smem;            // 2 x WORDS
-    uint32_t* pre = bits_buf + 2 * WORDS;            // WORDS
-    double* vals = (double*)(pre + WORDS);           // VALS
-    int32_t* tmp = (int32_t*)(vals + VALS);          // 2 x NW
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row = list[blockIdx.x];
-    const int a0 = a_ip[row];
-    const int lenA = a_ip[row + 1] - a0;
-    const int64_t tstride = (int64_t)nbase + 1;
-    const int lgE = lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
-    const int E = 1 << lgE, LA = 64 >> lgE;
-    const int npass = (lenA + E * NW - 1) / (E * NW);
-    const bool cached = npass == 1;
-    const int el = lane & (E - 1), pi = lane >> lgE;
-
-    // table windows per LDS window: about VALS products, at most the bitmap width, and every
-    // thread owns at least one bitmap word
-    int m = (WORDS * 32) >> shift;
-    {
-        const int m_min = (THREADS * 32) >> shift > 1 ? (THREADS * 32) >> shift : 1;
-        const long long q = prod[row] / nbase;
-        while (m > m_min && q * m > (long long)VALS) m >>= 1;
-    }
-    const int wpt = ((m << shift) >> 5) / THREADS;
-    int64_t out = c_ip[row] - c_ip[row_beg];
-
-    const int32_t* Tp = winptr;
-    double av = 0.0;
-    int t_cur = 0, t_nxt = 0;
-    bool have = false;
-    if (cached) {
-        const int e = el * NW + wv;
-        have = e < lenA;
-        if (have) {
-            Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
-            av = a_val[a0 + e];
-            t_cur = Tp[0];
-            t_nxt = Tp[m < nbase ? m : nbase];
-        }
-    }
-    for (int i = tid; i < 2 * WORDS; i += THREADS) bits_buf[i] = 0u;
-    for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
-    __syncthreads();
-
-    int flip = 0;
-    for (int w0 = 0; w0 < nbase; w0 += m) {
-        const int w1 = w0 + m < nbase ? w0 + m : nbase;
-        const int wbase = w0 << shift;
-        flip ^= 1;
-        uint32_t* bits = bits_buf + flip * WORDS;
-        int s_c = 0, len_c = 0;
-        if (cached) {
-            s_c = t_cur;
-            len_c = t_nxt - t_cur;
-            t_cur = t_nxt;
-            if (have && w1 < nbase) t_nxt = Tp[w1 + m < nbase ? w1 + m : nbase];
-        }
-        // ---- sweep 1: one bit per touched column ------------------------------
-        for (int c = 0; c < npass; c++) {
-            int s = s_c, len = len_c;
-            if (!cached) {
-                const int e = ((c << lgE) + el) * NW + wv;
-                len = 0;
-                if (e < lenA) {
-                    const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
-                    s = Tq[w0];
-                    len = Tq[w1] - s;
-                }
-            }
-            const bool v0 = pi < len, v1 = pi + LA < len;
-            const int q0 = v0 ? b_ix[s + pi] - wbase : 0;
-            const int q1 = v1 ? b_ix[s + pi + LA] - wbase : 0;
-            if (v0) atomicOr(&bits[q0 >> 5], 1u << (q0 & 31));
-            if (v1) atomicOr(&bits[q1 >> 5], 1u << (q1 & 31));
-            sweep_tiers23<false>(b_ix, b_val, s + 2 * LA, lane < E ? len - 2 * LA : 0, 0.0, lane, [&](int col, double) {
-                const int lc = col - wbase;
-                atomicOr(&bits[lc >> 5], 1u << (lc & 31));
-            });
-        }
-        __syncthreads();
-        // ---- rank prefix ---------------------------------------------------------
-        uint32_t myw[WPT];
-        int cntw, rbase;
-        {
-            int sum = 0;
-#pragma unroll
-            for (int j = 0; j < WPT; j++) {
-                myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
-                sum += __popc(myw[j]);
-            }
-            rbase = block_exclusive_scan_1b<THREADS, int32_t>(sum, tmp + flip * NW, &cntw);
-            int r = rbase;
-#pragma unroll
-            for (int j = 0; j < WPT; j++)
-                if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
-        }
-        if (cntw == 0) continue;   // block-uniform; nothing was marked, nothing to clear
-        for (int r0 = 0; r0 < cntw; r0 += VALS) {
-            const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
-            __syncthreads();   // rank prefix complete / accumulators of the previous pass written out
-            // ---- sweep 2: add the products whose rank falls into [r0, r0 + nsub) ----------
-            auto add = [&](int col, double v) {
-                const int lc = col - wbase;
-                const int r = (int)pre[lc >> 5] + __popc(bits[lc >> 5] & ((1u << (lc & 31)) - 1u)) - r0;
-                if ((unsigned)r < (unsigned)nsub) atomicAdd(&vals[r], v);
-            };
-            for (int c = 0; c < npass; c++) {
-                int s = s_c, len = len_c;
-                double a = av;
-                if (!cached) {
-                    const int e = ((c << lgE) + el) * NW + wv;
-                    len = 0;
-                    if (e < lenA) {
-                        const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
-                        s = Tq[w0];
-                        len = Tq[w1] - s;
-                        a = a_val[a0 + e];
-                    }
-                }
-                const bool v0 = pi < len, v1 = pi + LA < len;
-                const int q0 = v0 ? b_ix[s + pi] : 0;
-                const double x0 = v0 ? b_val[s + pi] : 0.0;
-                const int q1 = v1 ? b_ix[s + pi + LA] : 0;
-                const double x1 = v1 ? b_val[s + pi + LA] : 0.0;
-                if (v0) add(q0, a * x0);
-                if (v1) add(q1, a * x1);
-                sweep_tiers23<true>(b_ix, b_val, s + 2 * LA, lane < E ? len - 2 * LA : 0, a, lane, add);
-            }
-            __syncthreads();
-            // ---- write out ranks [r0, r0 + nsub) -----------------------------------
-            for (int r = tid; r < nsub; r += THREADS) {
-                c_val[out + r0 + r] = vals[r];
-                vals[r] = 0.0;
-            }
-            int r = rbase;
-#pragma unroll
-            for (int j = 0; j < WPT; j++) {
-                uint32_t bw = myw[j];
-                const int cb = wbase + (tid * wpt + j) * 32;
-                while (bw) {
-                    const int b = __ffs(bw) - 1;
-                    bw &= bw - 1u;
-                    if (r >= r0 && r < r0 + nsub) c_ix[out + r] = cb + b;
-                    r++;
-                }
-            }
-        }
-        // the other buffer serves the next window; this one is cleared for the one after
-#pragma unroll
-        for (int j = 0; j < WPT; j++)
-            if (j < wpt && myw[j]) bits[tid * wpt + j] = 0u;
-        out += cntw;
-    }
-}
-
-template <int THREADS, int WORDS, int VALS>
-constexpr size_t cmp_lds_bytes() { return (size_t)WORDS * 12 + (size_t)VALS * 8 + (size_t)(THREADS / 64) * 8; }
 
 // ---------------------------------------------------------------------------
 // Symbolic phase for window rows with the same barrier-free tiered sweep: the bitmap covers
@@ -1521,11 +1009,6 @@ constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16; }
 
 constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * 8; }
 
-template <int THREADS, int WORDS, int VALS>
-constexpr size_t num_lds_bytes() {
-    return (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 + (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64) * 8 + 16;
-}
-
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
     return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
@@ -1572,15 +1055,20 @@ struct Bins {
     int shift, nbase;
 };
 
-int table_shift(int32_t ncolB, int cfg, int num_cfg, int dense_min) {
-    if (cfg == 3) return 14;
-    if (num_cfg == 2) cfg = 4;   // a 256-thread numeric workgroup holds 64 Ki columns
-    // with dense rows enabled the table is as fine as the dense accumulators (2^14 columns) up to
-    // 1024 windows; otherwise 2^15 columns up to 256 windows
+// Column width of a table window: 2^14 columns (the width of the dense accumulators) while that
+// gives at most 1024 windows, wider beyond; 2^15 columns and at most 256 windows when the dense
+// kernel is switched off.
+int table_shift(int32_t ncolB, long long dense_min) {
     int shift = dense_min > 0 ? WIN_SHIFT_MIN : 15;
     const int max_windows = dense_min > 0 ? 1024 : 256;
-    while (shift < (cfg == 4 ? 16 : WIN_SHIFT_MAX) && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > max_windows) shift++;
+    while (shift < WIN_SHIFT_MAX && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > max_windows) shift++;
     return shift;
+}
+
+// rows with at least dense_min intermediate products use dense accumulators
+long long dense_threshold(const spmm_ctx* ctx) {
+    if (ctx->dense_min <= 0) return 0x7fffffffffffffffll;
+    return ctx->dense_min > 0xffffffffll ? 0xffffffffll : ctx->dense_min;   // the sort key of the row order saturates there
 }
 
 int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, bool fresh,
@@ -1603,7 +1091,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_MISC1, (size_t)nrow + 1, &key_w0));
     CHK(ws(ctx, WS_MISC2, (size_t)nrow + 1, &key_w1));
     CHK(ws(ctx, WS_LIST_WIN, (size_t)nrow + 1, &out->list_w));
-    out->shift = table_shift(B->ncol, ctx->win_cfg, ctx->num_cfg, ctx->dense_min);
+    out->shift = table_shift(B->ncol, ctx->dense_min);
     out->nbase = (int)(((int64_t)B->ncol + (1ll << out->shift) - 1) >> out->shift);
     if (out->nbase < 1) out->nbase = 1;
     const size_t table_elems = (size_t)B->nrow * ((size_t)out->nbase + 1);
@@ -1626,9 +1114,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
                            B->indices, counters);
     }
     int32_t nr = row_end - row_beg;
-    // rows with at least dense_min products per table window on average use dense accumulators
-    long long dense_thr = ctx->dense_min > 0 ? (long long)ctx->dense_min * out->nbase : 0x7fffffffffffffffll;
-    if (ctx->dense_min > 0 && dense_thr > 0xffffffffll) dense_thr = 0xffffffffll;   // the sort key saturates there
+    const long long dense_thr = dense_threshold(ctx);
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, row_beg, row_end,
                            out->prod, out->list_s, out->list_l, list_w0, key_w0, dense_thr, counters);
@@ -1672,68 +1158,25 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
-    if (NUMERIC && ctx->cmp_cfg > 0 && ctx->win_cfg == 0 && !ctx->win_stamps && !ctx->win_dbg) {
-        if (ctx->cmp_cfg == 2 && bins.shift <= 16) {   // two 512-thread workgroups per CU
-            constexpr size_t cl = cmp_lds_bytes<512, 2048, 4096>();
-            static_assert(2 * cl <= 160 * 1024, "two workgroups per CU");
-            auto kc = k_cmp<512, 2048, 4096>;
-            HIPCHK(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
-            hipLaunchKernelGGL(kc, dim3((unsigned)bins.n_w), dim3(512), cl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
-                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
-        } else {
-            constexpr size_t cl = cmp_lds_bytes<1024, 4096, 8192>();
-            static_assert(cl <= 160 * 1024, "LDS budget of one CU");
-            auto kc = k_cmp<1024, 4096, 8192>;
-            HIPCHK(hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
-            hipLaunchKernelGGL(kc, dim3((unsigned)bins.n_w), dim3(1024), cl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
-                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
-        }
-        return SPMM_OK;
-    }
-    const bool lean = NUMERIC && ctx->num_cfg >= 0 && ctx->win_cfg == 0 && !ctx->win_stamps && !ctx->win_dbg;
     auto kern = ctx->win_stamps ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (!lean)
     hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
                        A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
                        c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
                        (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0);
-    if (lean) {
-        int phw = phase_begin(ctx, SPMM_PH_WINDOW_NUM_NARROW);
-        if (ctx->num_cfg == 1) {          // two 512-thread workgroups per CU
-            constexpr size_t nl = num_lds_bytes<512, 4096, 4096>();
-            static_assert(2 * nl <= 160 * 1024, "two workgroups per CU");
-            auto kn = k_num<512, 4096, 4096, 8, 4>;
-            HIPCHK(hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl));
-            hipLaunchKernelGGL(kn, dim3((unsigned)bins.n_w), dim3(512), nl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
-                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
-        } else if (ctx->num_cfg == 2) {   // four 256-thread workgroups per CU
-            constexpr size_t nl = num_lds_bytes<256, 2048, 2048>();
-            static_assert(4 * nl <= 160 * 1024, "four workgroups per CU");
-            auto kn = k_num<256, 2048, 2048, 8, 4>;
-            HIPCHK(hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl));
-            hipLaunchKernelGGL(kn, dim3((unsigned)bins.n_w), dim3(256), nl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
-                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
-        } else {
-            constexpr size_t nl = num_lds_bytes<1024, 8192, 8192>();
-            static_assert(nl <= 160 * 1024, "LDS budget of one CU");
-            auto kn = k_num<1024, 8192, 8192, 8, 4>;
-            HIPCHK(hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl));
-            hipLaunchKernelGGL(kn, dim3((unsigned)bins.n_w), dim3(1024), nl, ctx->stream, bins.list_w, A->indptr, A->indices, A->data,
-                               B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, c_ip, row_beg, c_ix, c_val);
-        }
-        phase_end(ctx, phw);
-    }
     return SPMM_OK;
 }
 
+// Kernels per row class.  Symbolic: k_symd over all window rows (k_win when the table windows are
+// wider than its bitmap or SPMM_SYM_CFG=1).  Numeric: k_dense over the first n_dense rows of the
+// heaviest-first list, k_win over the rest.  Both phases: k_esc over the two light bins.
 template <bool NUMERIC>
 int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins_in, int32_t* rowcnt,
                 const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
     Bins bins = bins_in;
     if (NUMERIC && bins.n_dense > 0) {
-        int phd = phase_begin(ctx, SPMM_PH_WINDOW_NUM_NARROW);
+        int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
         static_assert(dl <= 160 * 1024, "LDS budget of one CU");
         auto kd = k_dense<1024>;
@@ -1757,28 +1200,8 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
     }
     if (bins.n_w > 0) {
         int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
-        if (ctx->win_cfg == 1) {
-            if constexpr (NUMERIC) CHK((launch_win<512, 4096, 4096, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<512, 16384, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        } else if (ctx->win_cfg == 5) {   // six products per lane
-            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 6, 2, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        } else if (ctx->win_cfg == 6) {   // four products per lane
-            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 4, 2, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        } else if (ctx->win_cfg == 3) {   // one wave per row, 16 K-column windows
-            if constexpr (NUMERIC) CHK((launch_win<64, 512, 512, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<64, 2048, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        } else if (ctx->win_cfg == 4) {   // 256 threads, four workgroups per CU
-            if constexpr (NUMERIC) CHK((launch_win<256, 2048, 2048, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<256, 8192, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        } else if (ctx->win_cfg == 2) {
-            if constexpr (NUMERIC) CHK((launch_win<512, 8192, 8192, 16, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<512, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        } else {
-            if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
-        }
+        if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
         phase_end(ctx, ph);
     }
     int ph_esc = phase_begin(ctx, NUMERIC ? SPMM_PH_ESC_NUM : SPMM_PH_ESC_SYM);
@@ -1808,6 +1231,17 @@ extern "C" int spmm_debug_stamps(spmm_ctx* ctx, unsigned long long* out, int res
     HIPCHK(hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->pinned, 32 * 8);
     if (reset) HIPCHK(hipMemsetAsync(stamps, 0, 32 * 8, ctx->stream));
+    return SPMM_OK;
+}
+
+extern "C" int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shift, int32_t* nbase, int64_t* dense_min_products) {
+    ARGCHK(ctx != nullptr && b_ncol >= 0);
+    const int sh = table_shift(b_ncol, ctx->dense_min);
+    int nb = (int)(((int64_t)b_ncol + (1ll << sh) - 1) >> sh);
+    if (nb < 1) nb = 1;
+    if (shift) *shift = sh;
+    if (nbase) *nbase = nb;
+    if (dense_min_products) *dense_min_products = dense_threshold(ctx);
     return SPMM_OK;
 }
 

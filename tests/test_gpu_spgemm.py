@@ -12,9 +12,32 @@ from tests.helpers import case_input, golden_json, golden_npz, hx
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = capi.Context(0)
+# Kernel selections the library reads from the environment when a context is created: the default
+# plan, every window row through the dense-accumulator kernel, the dense kernel off (cursor kernel
+# with 2^15-column table windows), and the cursor kernel for the symbolic phase with fixed-width
+# numeric windows.
+PLANS = {
+    "default": {},
+    "dense_all": {"SPMM_DENSE_MIN": "1"},
+    "dense_off": {"SPMM_DENSE_MIN": "0"},
+    "cursor_sym_fixed_windows": {"SPMM_SYM_CFG": "1", "SPMM_ADAPTIVE": "0"},
+}
+
+
+@pytest.fixture(scope="module", params=list(PLANS))
+def ctx(request):
+    import os
+    env = PLANS[request.param]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = capi.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     yield c
     c.close()
 
