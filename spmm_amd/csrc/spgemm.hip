@@ -323,7 +323,9 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     // at the front and idle at the back.  cs[j] = sum over the row's entries of the table value at
     // window j*gsz gives the products of any window range as a difference, and windows then grow
     // granule by granule while they hold at most U*THREADS products.
-    uint32_t* cs = (uint32_t*)(st_arr + 5 * NW);
+    uint32_t* cs = (uint32_t*)(st_arr + 5 * NW);   // 1024 + 2 entries
+    int32_t* wave_ent = (int32_t*)(cs + 1026);       // NW entries: entry (+1) that holds the first product of a wave's slice
+    uint16_t* emap = (uint16_t*)pre;                 // U*THREADS entries: product -> entry + 1 (fast windows; pre is free during the sweep)
     const int gsz = m_min;
     const int nh = (nbase + gsz - 1) / gsz;
     const int gmax = ((WORDS * 32) >> shift) / gsz;
@@ -385,13 +387,20 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         // registers of the one-pass form
         int cc[U];
         double pv[U];
-        unsigned okm = 0;
+        bool active = false;   // this wave holds products of a register-resident window
         bool fast = false;
         // ---- bit sweep: one bit per touched column ---------------------------
         // Single-chunk rows alternate between two directories, so the build needs no barrier in
         // front: the other buffer's last readers are at least one barrier behind.
         flip ^= 1;
         int2* dir = dir_buf + (single_chunk ? flip * (THREADS + 1) : 0);
+        if (NUMERIC && single_chunk) {
+            // product -> entry map of a register-resident window: cleared here, marked after the
+            // scan, both ordered by the barriers of the directory build
+            static_assert(!NUMERIC || (U == 8 && 2 * U * THREADS <= WORDS * 4), "one 16-byte store per thread clears the map");
+            ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < NW) wave_ent[tid] = 0;
+        }
         for (int c0 = 0; c0 < lenA; c0 += THREADS) {
             if (!single_chunk) __syncthreads();   // earlier readers of the directory are done
             int s = 0, len = 0;
@@ -415,51 +424,77 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                                          : block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
             dir[tid] = make_int2(off, s);
             if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
+            fast = NUMERIC && single_chunk && Tc <= U * THREADS;
+            // products per wave: register-resident windows give every wave a fixed slice of U*64
+            // products (waves past the end skip the window and issue nothing); the two-sweep form
+            // spreads the products evenly, in multiples of 64
+            const int per = fast ? U * 64 : ((Tc + NW - 1) / NW + 63) & ~63;
+            if (fast && len > 0) {
+                // mark where this entry's products start, and the slices that start inside it
+                emap[off] = (uint16_t)(tid + 1);
+                for (int b = off / (U * 64) + 1; b * (U * 64) < off + len; b++) wave_ent[b] = tid + 1;
+            }
             WIN_ARRIVE(2)
             __syncthreads();
             WIN_SKEW(2, 12)
             Tw += Tc;
             WIN_STAMP(0)   // directory
             if (Tc == 0) continue;
-            const int per = ((Tc + NW - 1) / NW + 63) & ~63;
             const int p_lo = wv * per;
             const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
-            fast = NUMERIC && single_chunk && Tc <= U * THREADS;
             if (p_lo >= p_hi) continue;   // this wave has no products in the chunk (wave-uniform)
-            WinCursor<THREADS> cur;
-            cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
             if (fast) {
+                // Straight-line code: lanes past the end of the slice repeat its last product with
+                // an empty bit mask and a zero addend.
+                active = true;
+                {
+                    // running maximum of the marks over the slice = entry (+1) of every product:
+                    // each lane scans U consecutive marks, the wave combines, the result goes back
+                    uint4* mine = (uint4*)(emap + p_lo + lane * U);
+                    const uint4 raw = *mine;
+                    int v[U] = {(int)(raw.x & 0xffffu), (int)(raw.x >> 16), (int)(raw.y & 0xffffu), (int)(raw.y >> 16),
+                                (int)(raw.z & 0xffffu), (int)(raw.z >> 16), (int)(raw.w & 0xffffu), (int)(raw.w >> 16)};
+#pragma unroll
+                    for (int i = 1; i < U; i++) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
+                    int inc = v[U - 1];
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int o = __shfl_up(inc, d, 64);
+                        inc = (lane >= d && o > inc) ? o : inc;
+                    }
+                    int before = __shfl_up(inc, 1, 64);
+                    const int wb = wave_ent[wv];
+                    before = (lane != 0 && before > wb) ? before : wb;
+#pragma unroll
+                    for (int i = 0; i < U; i++) v[i] = v[i] > before ? v[i] : before;
+                    *mine = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                       (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+                }
                 int pos[U];
-                double av = NUMERIC ? dir_av[cur.e] : 0.0;
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const int p = p_lo + j * 64 + lane;
-                    pos[j] = 0;
-                    pv[j] = 0.0;
-                    if (p < p_hi) {
-                        okm |= 1u << j;
-                        if (cur.seek(dir, p)) av = dir_av[cur.e];
-                        pos[j] = cur.start + (p - cur.off);
-                        pv[j] = av;
-                    }
+                    const int pc = p < p_hi ? p : p_hi - 1;
+                    const int e = (int)emap[pc] - 1;
+                    const int2 d = dir[e];
+                    pos[j] = d.y + (pc - d.x);
+                    pv[j] = dir_av[e];
                 }
                 double bv[U];
 #pragma unroll
                 for (int j = 0; j < U; j++) {
-                    cc[j] = 0;
-                    bv[j] = 0.0;
-                    if (okm & (1u << j)) {
-                        cc[j] = b_ix[pos[j]];
-                        bv[j] = b_val[pos[j]];
-                    }
+                    cc[j] = b_ix[pos[j]];
+                    bv[j] = b_val[pos[j]];
                 }
 #pragma unroll
-                for (int j = 0; j < U; j++)
-                    if (okm & (1u << j)) {
-                        atomicOr(&bits[(cc[j] - wbase) >> 5], 1u << ((cc[j] - wbase) & 31));
-                        pv[j] *= bv[j];
-                    }
+                for (int j = 0; j < U; j++) {
+                    const bool valid = p_lo + j * 64 + lane < p_hi;
+                    atomicOr(&bits[(cc[j] - wbase) >> 5], valid ? 1u << ((cc[j] - wbase) & 31) : 0u);
+                    pv[j] = valid ? pv[j] * bv[j] : 0.0;
+                }
             } else {
+                WinCursor<THREADS> cur;
+                cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
                 for (int pb = p_lo; pb < p_hi; pb += 64 * UG) {
                     int pos[UG];
                     unsigned ok = 0;
@@ -531,17 +566,20 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                 WIN_ARRIVE(1)
                 __syncthreads();   // rank prefix complete
                 WIN_SKEW(1, 11)
-                if (!(dbg & 8)) {
-                    // all rank look-ups first: LDS reads cannot move across the atomics, so one loop
-                    // would pay a full LDS round trip per product
+                if (active) {
+                    // All rank look-ups first: LDS reads cannot move across the atomics, so one
+                    // loop would pay a full LDS round trip per product.  The column id goes
+                    // straight to its rank in C (every product of a column stores the same
+                    // value), which spares the bit-by-bit walk over the bitmap.
 #pragma unroll
                     for (int j = 0; j < U; j++) {
-                        const int cj = (okm & (1u << j)) ? cc[j] - wbase : 0;
-                        cc[j] = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u));
+                        const int cj = cc[j] - wbase;
+                        const int rk = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u));
+                        c_ix[out + rk] = cc[j];
+                        cc[j] = rk;
                     }
 #pragma unroll
-                    for (int j = 0; j < U; j++)
-                        if ((okm & (1u << j)) && !(dbg & 1)) atomicAdd(&vals[cc[j]], pv[j]);
+                    for (int j = 0; j < U; j++) atomicAdd(&vals[cc[j]], pv[j]);
                 }
             } else {
                 // ---- value sweep: add the products of ranks [r0, r0+nsub) ----------
@@ -615,7 +653,9 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                     vals[r] = 0.0;
                 }
             WIN_STAMP(7)   // value store loop
-            if (staged) {
+            if (fast) {
+                // column ids were stored with the values' ranks
+            } else if (staged) {
                 // column ids through LDS (the rank prefix is no longer needed) for coalesced stores
                 int32_t* stage = (int32_t*)pre;
                 int r = ex;
@@ -653,6 +693,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         for (int j = 0; j < WPT; j++)
             if (j < wpt) bits[tid * wpt + j] = 0u;
         out += cntw;
+        if (NUMERIC && single_chunk && !fast) __syncthreads();   // staged column ids are read before the map is cleared
         WIN_STAMP(6)   // output
         // the next directory build starts with a barrier
     }
@@ -1013,7 +1054,7 @@ template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
     return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
            (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
-           (NUMERIC ? (size_t)(1024 + 2) * 4 : 0);   // adaptive-window sums: at most 1024 table windows
+           (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0);   // adaptive-window sums (at most 1024 table windows), wave bases
 }
 
 // ---------------------------------------------------------------------------
