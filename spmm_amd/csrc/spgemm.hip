@@ -469,6 +469,10 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                     for (int i = 0; i < U; i++) v[i] = v[i] > before ? v[i] : before;
                     *mine = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
                                        (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+                    // the other lanes of the wave read these entries next, without a barrier
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
                 int pos[U];
 #pragma unroll
@@ -732,6 +736,79 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
                             __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
+// Flattened wave-level sweep over what tier 1 left of the wave's entries: lanes hold (s, rem) =
+// start and count of the remaining products of their entry (rem <= 0: none).  The products of
+// all entries form one index space; a batch is 256 of them, four per lane, all loaded before
+// any is used.  wmap (256 bytes, private to the wave) maps a product of the batch to the lane
+// that holds its entry: entries mark the place where they start, a running maximum fills the
+// gaps.  act(col, a*b) is called once per product; b_val is only read when WITH_VAL.
+// The lanes of a wave exchange data through LDS without a workgroup barrier: LDS executes a
+// wave's instructions in order, so only the compiler has to be told that memory written by one
+// lane is read by another (it would otherwise forward a lane's own stores to its loads).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool WITH_VAL, typename F>
+__device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
+                                                int rem, double a, int lane, uint8_t* wmap, F&& act) {
+    uint32_t* wmap4 = (uint32_t*)wmap;
+    rem = rem > 0 ? rem : 0;
+    int inc = rem;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        inc += lane >= d ? o : 0;
+    }
+    const int R = __builtin_amdgcn_readlane(inc, 63);
+    const int o = inc - rem;     // index of the entry's first product
+    const int so = s - o;        // product q of this entry sits at so + q
+    for (int b0 = 0; b0 < R; b0 += 256) {
+        wmap4[lane] = 0u;
+        if (rem > 0 && o >= b0 && o < b0 + 256) wmap[o - b0] = (uint8_t)(lane + 1);
+        // the entry that holds product b0 when it started in an earlier batch (at most one lane)
+        const unsigned long long hold = __ballot(rem > 0 && o < b0 && o + rem > b0);
+        const int base = hold ? __ffsll(hold) : 0;
+        wave_sync_lds();   // the marks of the other lanes
+        const uint32_t raw = wmap4[lane];
+        int v0 = (int)(raw & 0xffu), v1 = (int)((raw >> 8) & 0xffu), v2 = (int)((raw >> 16) & 0xffu), v3 = (int)(raw >> 24);
+        v1 = v1 > v0 ? v1 : v0;
+        v2 = v2 > v1 ? v2 : v1;
+        v3 = v3 > v2 ? v3 : v2;
+        int run = v3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int x = __shfl_up(run, d, 64);
+            run = (lane >= d && x > run) ? x : run;
+        }
+        int before = __shfl_up(run, 1, 64);
+        before = (lane != 0 && before > base) ? before : base;
+        v0 = v0 > before ? v0 : before;
+        v1 = v1 > before ? v1 : before;
+        v2 = v2 > before ? v2 : before;
+        v3 = v3 > before ? v3 : before;
+        wmap4[lane] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+        wave_sync_lds();   // the filled map of the other lanes
+        int cq[4];
+        double bq[4], aq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = b0 + j * 64 + lane;
+            const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last product
+            const int src = (int)wmap[qc - b0] - 1;
+            const int pos = __shfl(so, src, 64) + qc;
+            aq[j] = WITH_VAL ? __shfl(a, src, 64) : 0.0;
+            cq[j] = b_ix[pos];
+            bq[j] = WITH_VAL ? b_val[pos] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (b0 + j * 64 + lane < R) act(cq[j], aq[j] * bq[j]);
+    }
+}
+
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                    const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
@@ -745,6 +822,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     double* acc = (double*)smem;
     uint8_t* flags = (uint8_t*)(acc + DENSE_COLS);
     int32_t* tmp = (int32_t*)(flags + DENSE_COLS);   // two scan buffers of NW, used alternately
+    uint8_t* wmap = (uint8_t*)(tmp + 2 * NW) + (threadIdx.x >> 6) * 256;   // 256 bytes per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = list[blockIdx.x];
@@ -828,34 +906,10 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     if (v1) dense_add(acc, flags, q1, cbase, a * r1);
                 }
                 const int rem = lane < E ? len - 2 * LA : 0;
-                unsigned long long mask_c = __ballot(rem > 128);
-                unsigned long long mask_b = __ballot(rem > 0 && rem <= 128);
-                // tier 2: 16 lanes per entry, four entries at a time
-                const int nb = __popcll(mask_b);
-                const int g = lane >> 4, sl = lane & 15;
-                for (int it = 0; it < nb; it += 4) {
-                    int l4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        l4[q] = mask_b ? __ffsll(mask_b) - 1 : 0;
-                        mask_b &= mask_b - 1;
-                    }
-                    const int src = g == 0 ? l4[0] : g == 1 ? l4[1] : g == 2 ? l4[2] : l4[3];
-                    // every lane takes part in the shuffles: a masked-off source lane would read as 0
-                    const int ss = __shfl(s, src, 64) + 2 * LA;
-                    const int rsrc = __shfl(rem, src, 64);
-                    const double aa = __shfl(a, src, 64);
-                    const int rr = it + g < nb ? rsrc : 0;
-                    for (int i = sl; i < rr; i += 32) {
-                        const bool v1 = i + 16 < rr;
-                        const int c0 = b_ix[ss + i];
-                        const double b0 = b_val[ss + i];
-                        const int c1 = v1 ? b_ix[ss + i + 16] : -1;
-                        const double b1 = v1 ? b_val[ss + i + 16] : 0.0;
-                        dense_add(acc, flags, c0, cbase, aa * b0);
-                        if (v1) dense_add(acc, flags, c1, cbase, aa * b1);
-                    }
-                }
+                unsigned long long mask_c = __ballot(rem > 256);
+                // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
+                wave_flat_sweep<true>(b_ix, b_val, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
+                                      [&](int col, double v) { dense_add(acc, flags, col, cbase, v); });
                 // tier 3: the whole wave on one entry
                 while (mask_c) {
                     const int src = __ffsll(mask_c) - 1;
@@ -1048,7 +1102,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 
 constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16; }
 
-constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * 8; }
+constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * (8 + 256); }
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
