@@ -195,6 +195,13 @@ def main():
             stamps["numeric"][f"skew_{nm}_barrier_cycles_per_window"] = round(float(st[sl] / max(st[24], 1)))
         stamps["numeric"]["cycles_per_window"] = round(float(st[16:24].sum() / max(st[24], 1)))
         stamps["symbolic"]["cycles_per_window"] = round(float(st[0:8].sum() / max(st[8], 1)))
+        # the dense kernel uses slots 0..5: sweep, wait for the sweep barrier, flags and sums, wait for the
+        # scan barrier, stores, windows
+        dn = ["sweep", "sweep_wait", "flags_sums", "scan_wait", "stores"]
+        stamps["dense"] = {n: round(float(st[i] / max(st[5], 1))) for i, n in enumerate(dn)}
+        stamps["dense"]["windows"] = int(st[5])
+        stamps["dense"]["sparse_windows"] = dict(count=int(st[6]), cycles_per_window=round(float(st[7] / max(st[6], 1))))
+        stamps["dense"]["full_windows"] = dict(count=int(st[8]), cycles_per_window=round(float(st[9] / max(st[8], 1))))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nnz_c_local)], dtype=torch.float64, device=dev)
     if dist is not None:

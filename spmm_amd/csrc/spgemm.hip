@@ -809,13 +809,14 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
     }
 }
 
-template <int THREADS>
+template <int THREADS, bool STAMP>
 __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                    const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                    const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
                                                    const int32_t* __restrict__ winptr, int nbase, int shift,
                                                    const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg) {
+                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg,
+                                                   unsigned long long* __restrict__ stamps) {
     constexpr int NW = THREADS / 64;
     static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -867,6 +868,11 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     }
     __syncthreads();
 
+    // diagnostic build: cycles of thread 0 per section (0 sweep, 1 wait for the sweep barrier,
+    // 2 flags and sums, 3 wait for the scan barrier, 4 stores, 5 windows)
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_w = 0;   // 6..9: windows with < 1024 / >= 1024 entries of C: count, cycles
+    if (STAMP && tid == 0) st_w = st_t = win_clock();
+#define DENSE_STAMP(i) if (STAMP && tid == 0) { const unsigned long long n_ = win_clock(); st[i] += n_ - st_t; st_t = n_; }
     int flip = 0;
     for (int w = 0; w < nbase; w++) {
         int s_c = 0, len_c = 0;
@@ -892,6 +898,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                         a = a_val[a0 + e];
                     }
                 }
+                if (__ballot(len > 0) == 0ull) continue;   // nothing of this wave's entries falls into the window
                 // tier 1: products pi and pi+LA of the lane's own entry
                 if (pipelined) {
                     if (pi < len) dense_add(acc, flags, pc0, cbase, a * pb0);
@@ -938,7 +945,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 if (pi < len) { pc0 = b_ix[t_cur + pi]; pb0 = b_val[t_cur + pi]; }
                 if (pi + LA < len) { pc1 = b_ix[t_cur + pi + LA]; pb1 = b_val[t_cur + pi + LA]; }
             }
+            DENSE_STAMP(0)
             __syncthreads();
+            DENSE_STAMP(1)
             // ---- output: thread t owns columns [16t, 16t+16) of the window ----------------
             const uint4 f = ((const uint4*)flags)[tid];
             // flag bytes are 0 or 1: the multiply gathers the four low bits of a word into bits 24..27
@@ -948,7 +957,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             // can start right after it
             double vr[16];
             if (m16) ((uint4*)flags)[tid] = make_uint4(0u, 0u, 0u, 0u);
-            {
+            const bool wave_has = __ballot(m16 != 0u) != 0ull;
+            if (wave_has) {
                 unsigned mm = m16;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
@@ -963,8 +973,10 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             }
             flip ^= NW;
             int total;
+            DENSE_STAMP(2)
             int r = block_exclusive_scan_1b<THREADS, int32_t>(__popc(m16), tmp + flip, &total);
-            {
+            DENSE_STAMP(3)
+            if (wave_has) {
                 unsigned mm = m16;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
@@ -978,8 +990,19 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 }
             }
             out += total;
+            DENSE_STAMP(4)
+            if (STAMP && tid == 0) {
+                st[5] += 1;
+                const int cls = total < 1024 ? 6 : 8;
+                st[cls] += 1;
+                st[cls + 1] += st_t - st_w;
+                st_w = st_t;
+            }
         }
     }
+    if (STAMP && tid == 0)
+        for (int i = 0; i < 10; i++) atomicAdd(&stamps[i], st[i]);
+#undef DENSE_STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -1274,10 +1297,13 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
         static_assert(dl <= 160 * 1024, "LDS budget of one CU");
-        auto kd = k_dense<1024>;
+        auto kd = ctx->win_stamps ? k_dense<1024, true> : k_dense<1024, false>;
+        unsigned long long* stamps;
+        CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
         hipLaunchKernelGGL(kd, dim3((unsigned)bins.n_dense), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr, A->indices,
-                           A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix, c_val, ctx->win_dbg >> 8);
+                           A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix, c_val, ctx->win_dbg >> 8,
+                           stamps);
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;
         bins.n_w -= bins.n_dense;
