@@ -237,8 +237,21 @@ def main():
     bytes_w = 12 * P_w + 20 * nnzA_w + 12 * (rows_w + 1) + 12 * nnzC_w
     t_w_ms = times[kname][0] / args.steps
     achieved = bytes_w / (t_w_ms * 1e-3) / 1e9 if t_w_ms > 0 else 0.0
+    # HBM bytes per launch from PMC counters cannot be collected inside this process: they come from
+    # separate rocprofv3 --pmc passes over this same command, stored under profiles/ per workload.
+    workload = f"R-MAT scale {args.scale} edge factor {args.edge_factor} seed {args.seed}, C=A*A, all values 1.0"
+    traffic = None
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic*.json"))):
+        try:
+            T = json.load(open(f))
+            if T.get("workload") == workload and kname in T.get("kernels", {}) and world == 1:
+                traffic = T["kernels"][kname]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=bytes_w // max(times[kname][1] // max(args.steps, 1), 1),
                     algorithmic_bytes_per_step=bytes_w, kernel_ms_per_step=round(t_w_ms, 3),
                     launches_per_step=times[kname][1] // max(args.steps, 1),
                     rows=rows_w, products=P_w, nnz_c=nnzC_w,
@@ -275,7 +288,7 @@ def main():
     out = dict(metric="spgemm_gflops", value=round(gflops, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload=f"R-MAT scale {args.scale} edge factor {args.edge_factor} seed {args.seed}, C=A*A, all values 1.0",
+               config=dict(workload=workload,
                            rows=n, nnz=nnz, products=P_total, nnz_c=nnz_c_total, partition="rows of A by product count",
                            step="symbolic+numeric", c_row_blocks_per_step=state["blocks"], rank0_rows=rows_l,
                            b_allgather_ms=round(b_allgather_ms, 3), setup_s=round(setup_s, 1)),
