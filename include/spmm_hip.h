@@ -82,9 +82,9 @@ enum {
 };
 int spmm_ctx_profile(spmm_ctx* ctx, int enable);
 int spmm_ctx_phase_ms(spmm_ctx* ctx, int phase, double* total_ms, int* launches);
-/* Row-bin limits of the product: rows with at most *esc_small / *esc_large intermediate products
- * are handled by the 64-lane / 256-thread expand-sort-compress kernels, heavier rows by the
- * window kernel. */
+/* Row-bin limits of the product: rows with at most *esc_small intermediate products are handled
+ * by the 64-lane expand-sort-compress kernel, rows with at most *esc_large by the larger
+ * expand-sort-compress kernels, heavier rows by the window kernels. */
 void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
 /* Plan parameters the context would use for a right-hand matrix with b_ncol columns: the window
  * table has *nbase windows of 2^*shift columns per row of B, and rows of A with at least

@@ -42,7 +42,7 @@ void spmm_set_error(const char* fmt, ...);
 // calls of the same size allocate nothing.
 enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
-    WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
+    WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_ESC_M, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
     WS_WINPTR, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_P0, WS_P1, WS_P2, WS_P3, WS_P4, WS_P5, WS_P6, WS_P7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     WS_NSLOTS

@@ -24,11 +24,21 @@ namespace {
 
 constexpr int ESC_S_CAP = 512;
 constexpr int ESC_L_CAP = 4096;
+constexpr int ESC_R_CAP = 8192;         // radix expand-sort-compress: rows with up to this many products and 65535 entries
 constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14 .. 2^17 columns
 constexpr int WIN_SHIFT_MAX = 17;
 constexpr int KEY_PAD = 0x7fffffff;
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_N = 8 };
+// The lanes of a wave exchange data through LDS without a workgroup barrier: LDS executes a
+// wave's instructions in order, so only the compiler has to be told that memory written by one
+// lane is read by another (it would otherwise forward a lane's own stores to its loads).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_N = 8 };
 
 // ---------------------------------------------------------------------------
 // P_i per row, one wave per row.
@@ -71,14 +81,20 @@ __global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol
 
 // Bin rows [row_beg,row_end) by P_i.
 __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_end, const int64_t* __restrict__ prod,
+                                                  const int32_t* __restrict__ a_ip,
                                                   int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
+                                                  int32_t* __restrict__ list_m,
                                                   int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
                                                   long long dense_thr, long long* __restrict__ counters) {
     int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
     if (row < row_end) {
         p = prod[row];
-        if (p > ESC_L_CAP) {
+        // the radix expand-sort-compress kernels index the entries of a row with 16 bits
+        const bool many_entries = a_ip[row + 1] - a_ip[row] > 65535;
+        if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) {
+            list_m[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_M], 1ull)] = (int32_t)row;
+        } else if (p > ESC_L_CAP || (p > ESC_S_CAP && many_entries)) {
             int at = (int)atomicAdd((unsigned long long*)&counters[CNT_WIN], 1ull);
             list_w[at] = (int32_t)row;
             key_w[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);   // ascending key = descending P
@@ -167,6 +183,189 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
         outrun += tot;
     }
     if (!NUMERIC && tid == 0) rowcnt[row] = outrun;
+}
+
+// ---------------------------------------------------------------------------
+// Expand / radix sort / compress in LDS for rows with up to CAP products, whatever their column
+// span (the window kernels pay per column window, and a light row of a wide matrix has few
+// products in each).  Products are expanded as (column id, index); the pairs go through a stable
+// LSD radix sort on 8-bit digits (per wave: ranks by ballot match and digit counters in LDS; per
+// workgroup: one scan over [digit][wave]); equal columns end adjacent in product order, so the
+// sums add in the order of the serial algorithm.  Values are not carried through the sort: the
+// compress step reads a*b through the sorted index (position in B and entry of A per product).
+template <int THREADS, int CAP, bool NUMERIC>
+__global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                  const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                                  const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val, int key_bits) {
+    constexpr int NW = THREADS / 64;
+    constexpr int EPT = CAP / THREADS;        // elements per thread
+    constexpr int CPW = CAP / NW;             // elements per wave in a sort pass
+    constexpr int QCAP = CAP / 64;            // entries with at least 64 products
+    static_assert(CPW == 64 * EPT && (256 * NW) % THREADS == 0, "geometry");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* key_a = (uint32_t*)smem;
+    uint32_t* key_b = key_a + CAP;
+    uint16_t* idx_a = (uint16_t*)(key_b + CAP);                 // NUMERIC
+    uint16_t* idx_b = idx_a + (NUMERIC ? CAP : 0);              // NUMERIC
+    uint32_t* ppos = (uint32_t*)(idx_b + (NUMERIC ? CAP : 0));  // NUMERIC: position of the product in B
+    uint16_t* pent = (uint16_t*)(ppos + (NUMERIC ? CAP : 0));   // NUMERIC: entry of the A row
+    uint16_t* cnt = pent + (NUMERIC ? CAP : 0);                 // [NW][256] digit counters, then offsets
+    int4* queue = (int4*)(cnt + NW * 256);                      // (offset, start in B, length, entry)
+    int32_t* tmp = (int32_t*)(queue + QCAP);                    // scan buffer NW + 1, queue length
+    int32_t* qlen = tmp + NW + 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row], lenA = a_ip[row + 1] - a0;
+
+    // ---- expand ------------------------------------------------------------------
+    int run = 0;
+    for (int e0 = 0; e0 < lenA; e0 += THREADS) {
+        const int e = e0 + tid;
+        int len = 0, b0 = 0;
+        if (e < lenA) {
+            const int k = a_ix[a0 + e];
+            b0 = b_ip[k];
+            len = b_ip[k + 1] - b0;
+        }
+        if (tid == 0) *qlen = 0;
+        int tot;
+        const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;   // barriers inside
+        if (len >= 64) {
+            queue[atomicAdd(qlen, 1)] = make_int4(off, b0, len, e);      // long runs: the whole workgroup copies them
+        } else {
+            for (int q = 0; q < len; q++) {
+                key_a[off + q] = (uint32_t)b_ix[b0 + q];
+                if (NUMERIC) { ppos[off + q] = (uint32_t)(b0 + q); pent[off + q] = (uint16_t)e; }
+            }
+        }
+        __syncthreads();
+        const int nq = *qlen;
+        for (int qi = 0; qi < nq; qi++) {
+            const int4 it = queue[qi];
+            for (int i = tid; i < it.z; i += THREADS) {
+                key_a[it.x + i] = (uint32_t)b_ix[it.y + i];
+                if (NUMERIC) { ppos[it.x + i] = (uint32_t)(it.y + i); pent[it.x + i] = (uint16_t)it.w; }
+            }
+        }
+        run += tot;
+        __syncthreads();
+    }
+    const int N = run;
+    if (NUMERIC)
+        for (int i = tid; i < N; i += THREADS) idx_a[i] = (uint16_t)i;
+    __syncthreads();
+
+    // ---- stable LSD radix sort of (key, idx) --------------------------------------
+    uint32_t* ks = key_a;
+    uint32_t* kd = key_b;
+    uint16_t* is = idx_a;
+    uint16_t* id = idx_b;
+    uint16_t* mycnt = cnt + wv * 256;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        ((uint64_t*)mycnt)[lane] = 0ull;          // 256 counters of 16 bits per wave
+        wave_sync_lds();
+        uint32_t k[EPT];
+        int lrank[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            if (wv * CPW + r * 64 >= N) break;    // wave-uniform: nothing of this round is in use
+            const int i = wv * CPW + r * 64 + lane;
+            const bool valid = i < N;
+            k[r] = valid ? ks[i] : 0xffffffffu;
+            const unsigned d = (k[r] >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            // the first lane of each group of equal digits advances the wave's counter
+            const int leader = valid ? __ffsll(peers) - 1 : lane;
+            int old = 0;
+            if (valid && lane == leader) {
+                old = mycnt[d];
+                mycnt[d] = (uint16_t)(old + __popcll(peers));
+            }
+            old = __shfl(old, leader, 64);
+            lrank[r] = old + __popcll(peers & lt_mask);
+            wave_sync_lds();
+        }
+        __syncthreads();
+        // exclusive scan over [digit][wave] in place: thread t owns 256*NW/THREADS consecutive cells
+        {
+            constexpr int CPT = 256 * NW / THREADS;
+            int v[CPT], sum = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int cell = tid * CPT + j;               // = digit * NW + wave
+                v[j] = cnt[(cell % NW) * 256 + cell / NW];
+                sum += v[j];
+            }
+            int tot;
+            int base = block_exclusive_scan<THREADS, int32_t>(sum, tmp, &tot);   // barriers inside: all reads done
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int cell = tid * CPT + j;
+                cnt[(cell % NW) * 256 + cell / NW] = (uint16_t)base;
+                base += v[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            const int i = wv * CPW + r * 64 + lane;
+            if (i < N) {
+                const int dest = (int)mycnt[(k[r] >> shift) & 255u] + lrank[r];
+                kd[dest] = k[r];
+                if (NUMERIC) id[dest] = is[i];
+            }
+        }
+        __syncthreads();
+        uint32_t* tk = ks; ks = kd; kd = tk;
+        uint16_t* ti = is; is = id; id = ti;
+    }
+
+    // ---- compress: one output entry per run of equal columns -------------------------
+    int64_t obase = 0;
+    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
+    int heads = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+        const int i = tid * EPT + j;
+        heads += (i < N && (i == 0 || ks[i - 1] != ks[i])) ? 1 : 0;
+    }
+    int total;
+    int r = block_exclusive_scan<THREADS, int32_t>(heads, tmp, &total);
+    if (NUMERIC) {
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int i = tid * EPT + j;
+            if (i < N && (i == 0 || ks[i - 1] != ks[i])) {
+                const uint32_t key = ks[i];
+                double sum = 0.0;
+                for (int u = i; u < N && ks[u] == key; u++) {
+                    const int q = is[u];
+                    sum += a_val[a0 + pent[q]] * b_val[ppos[q]];
+                }
+                c_ix[obase + r] = (int32_t)key;
+                c_val[obase + r] = sum;
+                r++;
+            }
+        }
+    } else if (tid == 0) {
+        rowcnt[row] = total;
+    }
+}
+
+template <int THREADS, int CAP, bool NUMERIC>
+constexpr size_t escr_lds_bytes() {
+    return (size_t)CAP * (NUMERIC ? 8 + 4 + 4 + 2 : 8) + (size_t)(THREADS / 64) * 512 + (size_t)(CAP / 64) * 16 +
+           (size_t)(THREADS / 64 + 2) * 4;
 }
 
 // ---------------------------------------------------------------------------
@@ -742,15 +941,6 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // any is used.  wmap (256 bytes, private to the wave) maps a product of the batch to the lane
 // that holds its entry: entries mark the place where they start, a running maximum fills the
 // gaps.  act(col, a*b) is called once per product; b_val is only read when WITH_VAL.
-// The lanes of a wave exchange data through LDS without a workgroup barrier: LDS executes a
-// wave's instructions in order, so only the compiler has to be told that memory written by one
-// lane is read by another (it would otherwise forward a lane's own stores to its loads).
-__device__ __forceinline__ void wave_sync_lds() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <bool WITH_VAL, typename F>
 __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
                                                 int rem, double a, int lane, uint8_t* wmap, F&& act) {
@@ -1167,8 +1357,8 @@ int check_csr_args(const spmm_csr* M) {
 // with the same device arrays as the last symbolic call (the normal sequence).
 struct Bins {
     int64_t* prod;
-    int32_t *list_s, *list_l, *list_w;
-    long long n_s, n_l, n_w, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
+    int32_t *list_s, *list_l, *list_m, *list_w;
+    long long n_s, n_l, n_m, n_w, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
 };
@@ -1203,6 +1393,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_PROD, (size_t)nrow + 1, &out->prod));
     CHK(ws(ctx, WS_LIST_ESC_S, (size_t)nrow + 1, &out->list_s));
     CHK(ws(ctx, WS_LIST_ESC_L, (size_t)nrow + 1, &out->list_l));
+    CHK(ws(ctx, WS_LIST_ESC_M, (size_t)nrow + 1, &out->list_m));
     int32_t* list_w0;
     uint32_t *key_w0, *key_w1;
     CHK(ws(ctx, WS_MISC0, (size_t)nrow + 1, &list_w0));
@@ -1235,7 +1426,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     const long long dense_thr = dense_threshold(ctx);
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, row_beg, row_end,
-                           out->prod, out->list_s, out->list_l, list_w0, key_w0, dense_thr, counters);
+                           out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, counters);
     long long* h = (long long*)ctx->pinned;
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1249,6 +1440,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     out->n_s = h[CNT_ESC_S];
     out->n_l = h[CNT_ESC_L];
+    out->n_m = h[CNT_ESC_M];
     out->n_w = h[CNT_WIN];
     out->n_dense = h[CNT_DENSE];
     out->products = h[CNT_PRODUCTS];
@@ -1326,9 +1518,24 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         phase_end(ctx, ph);
     }
     int ph_esc = phase_begin(ctx, NUMERIC ? SPMM_PH_ESC_NUM : SPMM_PH_ESC_SYM);
-    if (bins.n_l > 0)
-        hipLaunchKernelGGL((k_esc<256, ESC_L_CAP, NUMERIC>), dim3((unsigned)bins.n_l), dim3(256), 0, ctx->stream, bins.list_l,
-                           A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
+    if (bins.n_m > 0) {
+        constexpr size_t rl = escr_lds_bytes<1024, ESC_R_CAP, NUMERIC>();
+        static_assert(rl <= 160 * 1024, "LDS budget of one CU");
+        auto kr = k_escr<1024, ESC_R_CAP, NUMERIC>;
+        HIPCHK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+        hipLaunchKernelGGL(kr, dim3((unsigned)bins.n_m), dim3(1024), rl, ctx->stream, bins.list_m, A->indptr, A->indices, A->data,
+                           B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
+                           bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+    }
+    if (bins.n_l > 0) {
+        constexpr size_t rl = escr_lds_bytes<512, ESC_L_CAP, NUMERIC>();
+        static_assert(2 * rl <= 160 * 1024, "two workgroups per CU");
+        auto kr = k_escr<512, ESC_L_CAP, NUMERIC>;
+        HIPCHK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+        hipLaunchKernelGGL(kr, dim3((unsigned)bins.n_l), dim3(512), rl, ctx->stream, bins.list_l, A->indptr, A->indices, A->data,
+                           B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
+                           bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+    }
     if (bins.n_s > 0)
         hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)bins.n_s), dim3(64), 0, ctx->stream, bins.list_s,
                            A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
@@ -1368,7 +1575,7 @@ extern "C" int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shi
 
 extern "C" void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large) {
     if (esc_small) *esc_small = ESC_S_CAP;
-    if (esc_large) *esc_large = ESC_L_CAP;
+    if (esc_large) *esc_large = ESC_R_CAP;
 }
 
 extern "C" int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* prod, int64_t* total) {
@@ -1422,7 +1629,7 @@ extern "C" int spmm_spgemm_numeric_dev(spmm_ctx* ctx, const spmm_csr* A, const s
     if (row_beg == row_end) return SPMM_OK;
     Bins bins;
     CHK(build_bins(ctx, A, B, row_beg, row_end, false, &bins));
-    ARGCHK(bins.n_s + bins.n_l + bins.n_w == 0 || (c_indices != nullptr && c_data != nullptr));
+    ARGCHK(bins.n_s + bins.n_l + bins.n_m + bins.n_w == 0 || (c_indices != nullptr && c_data != nullptr));
     CHK(launch_rows<true>(ctx, A, B, bins, nullptr, c_indptr, row_beg, c_indices, c_data));
     return SPMM_OK;
 }
