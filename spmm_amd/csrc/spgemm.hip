@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ li
                 sum += v[j];
             }
             int tot;
-            int base = block_exclusive_scan<THREADS, int32_t>(sum, tmp, &tot);   // barriers inside: all reads done
+            int base = block_exclusive_scan_1b<THREADS, int32_t>(sum, tmp, &tot);   // a barrier inside: all reads done
 #pragma unroll
             for (int j = 0; j < CPT; j++) {
                 const int cell = tid * CPT + j;
@@ -1519,11 +1519,13 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
     }
     int ph_esc = phase_begin(ctx, NUMERIC ? SPMM_PH_ESC_NUM : SPMM_PH_ESC_SYM);
     if (bins.n_m > 0) {
-        constexpr size_t rl = escr_lds_bytes<1024, ESC_R_CAP, NUMERIC>();
+        // numeric gains from 1024 threads in the gathering compress step, symbolic from cheaper barriers
+        constexpr int RT = NUMERIC ? 1024 : 512;
+        constexpr size_t rl = escr_lds_bytes<RT, ESC_R_CAP, NUMERIC>();
         static_assert(rl <= 160 * 1024, "LDS budget of one CU");
-        auto kr = k_escr<1024, ESC_R_CAP, NUMERIC>;
+        auto kr = k_escr<RT, ESC_R_CAP, NUMERIC>;
         HIPCHK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-        hipLaunchKernelGGL(kr, dim3((unsigned)bins.n_m), dim3(1024), rl, ctx->stream, bins.list_m, A->indptr, A->indices, A->data,
+        hipLaunchKernelGGL(kr, dim3((unsigned)bins.n_m), dim3(RT), rl, ctx->stream, bins.list_m, A->indptr, A->indices, A->data,
                            B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
                            bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
     }
