@@ -132,6 +132,37 @@ typedef struct {
 } spmm_trace;
 int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t threshold, spmm_trace* out);
 
+/* ---- the stages of the pipeline one by one (HOST pointers, caller-allocated outputs).  Each
+ *      call uploads its inputs, runs the stage on the GPU and downloads the outputs;
+ *      spmm_last_kernel_ms() gives the kernel time of the last call.  Chaining them reproduces
+ *      spmm_trace_formats, which keeps the intermediate arrays on the device instead. */
+/* a3, replaces bitmap_reorder() (bitmap.h:108-170): row key per SECT-column section, stable bucket
+ * by key, row gather.  seq[nrow] (new row -> old row), r_indptr[nrow+1], r_indices[nnz], r_data[nnz]
+ * are caller-allocated. */
+int spmm_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* seq, int32_t* r_indptr,
+                        int32_t* r_indices, double* r_data);
+/* a4, replaces gen_new_panels() (transmat.h:334-376): greedy row blocks of at least `threshold`
+ * distinct columns.  bsize_list has room for cap entries (block boundaries, first 0, last nrow);
+ * SPMM_E_CAPACITY instead of the reference's overflow when more are needed. */
+int spmm_gen_blocks(spmm_ctx* ctx, const spmm_csr* R, int32_t threshold, int32_t* bsize_list, int32_t cap, int32_t* bnum);
+/* a5-a7, replaces gen_panel_list() + panel_sort_nnz() (v8sort.h:49-73, 152-232) and the block
+ * gather with the 8-row interleave (serial_newblock_clock.cpp:336-399).  Sizes as in spmm_trace. */
+int spmm_panels_sort_pack(spmm_ctx* ctx, const spmm_csr* R, const int32_t* bsize_list, int32_t bnum,
+                          int32_t* panel_ptr, int32_t* panel_list, int32_t* n_panel_entries, int32_t* spv8_list,
+                          int32_t* n_spv8, int32_t* out_seq_all, int32_t* b_indptr, int32_t* b_colidx_orig, double* b_data);
+/* a8, replaces gen_serial_origin_vec() (serial_newblock_clock.cpp:187-204): first-touch local column
+ * ids per block over the packed column stream.  b_local[nnz], keys[nnz] (*n_keys used),
+ * seq_offset[bnum+1]. */
+int spmm_first_touch(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* r_indptr,
+                     const int32_t* bsize_list, int32_t bnum, const int32_t* b_colidx_orig, int32_t* b_local,
+                     int32_t* keys, int32_t* n_keys, int32_t* seq_offset);
+/* a9, replaces gen_rseq() / SeqReverse() / SerialSort_block_vec() (wbsort.h:58-67, 16-34, 81-95):
+ * rseq[nrow] (original row -> final position), seq_input[n_keys] = rseq[keys[i]].  Requires every key
+ * to be a valid row id (ncol <= nrow). */
+int spmm_wbseq(spmm_ctx* ctx, int32_t nrow, const int32_t* seq_bitmap, const int32_t* out_seq_all,
+               const int32_t* bsize_list, int32_t bnum, const int32_t* keys, int32_t n_keys, int32_t* seq_input,
+               int32_t* rseq);
+
 /* ---- sparse product C = A*B (not present in the reference; implied by wbsort.h:87-88,
  *      where B = A).  B's rows must have ascending column ids (duplicates allowed).
  *      symbolic: c_indptr[A.nrow+1] (int64), *nnz_c and *products (intermediate products,

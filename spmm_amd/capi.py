@@ -181,6 +181,56 @@ class Context:
                    keys=a["keys"][:nk].copy(), seq_input=a["seq_input"][:nk].copy())
         return out
 
+    # ---- the stages one by one (host arrays) ---------------------------------------
+    def bitmap_reorder(self, A, sect=2048):
+        """a3 (bitmap.h:108-170) -> (seq, Csr of the reordered matrix)."""
+        seq = np.empty(A.nrow, I32)
+        ip, ix, d = np.empty(A.nrow + 1, I32), np.empty(A.nnz, I32), np.empty(A.nnz, F64)
+        va = A.view()
+        _chk(lib().spmm_bitmap_reorder(self._h, C.byref(va), C.c_int32(sect), _p(seq), _p(ip), _p(ix), _p(d)))
+        return seq, Csr(A.nrow, A.ncol, ip, ix, d)
+
+    def gen_blocks(self, R, threshold=65536, cap=None):
+        """a4 (transmat.h:334-376) -> bsize_list (bnum + 1 entries)."""
+        cap = cap if cap is not None else max(2, min(R.nrow + 2, 1 << 20))
+        bsize, bnum = np.empty(cap, I32), C.c_int32()
+        vr = R.view()
+        _chk(lib().spmm_gen_blocks(self._h, C.byref(vr), C.c_int32(threshold), _p(bsize), C.c_int32(cap), C.byref(bnum)))
+        return bsize[:bnum.value + 1].copy()
+
+    def panels_sort_pack(self, R, bsize_list):
+        """a5-a7 (v8sort.h:49-73, 152-232; serial_newblock_clock.cpp:336-399)."""
+        bsize_list = _np(bsize_list, I32)
+        b, n, z = bsize_list.size - 1, R.nrow, R.nnz
+        a = dict(panel_ptr=np.empty(b + 1, I32), panel_list=np.empty(n // 8 + 3 * b + 8, I32),
+                 spv8_list=np.empty(n // 8 + 3 * b + 8, I32), out_seq_all=np.empty(n, I32), b_indptr=np.empty(n + b, I32),
+                 b_colidx_orig=np.empty(z, I32), b_data=np.empty(z, F64))
+        nl, ns = C.c_int32(), C.c_int32()
+        vr = R.view()
+        _chk(lib().spmm_panels_sort_pack(self._h, C.byref(vr), _p(bsize_list), C.c_int32(b), _p(a["panel_ptr"]),
+                                         _p(a["panel_list"]), C.byref(nl), _p(a["spv8_list"]), C.byref(ns),
+                                         _p(a["out_seq_all"]), _p(a["b_indptr"]), _p(a["b_colidx_orig"]), _p(a["b_data"])))
+        a["panel_list"] = a["panel_list"][:nl.value].copy()
+        a["spv8_list"] = a["spv8_list"][:ns.value].copy()
+        return a
+
+    def first_touch(self, R, bsize_list, b_colidx_orig):
+        """a8 (serial_newblock_clock.cpp:187-204) -> (b_local, keys, seq_offset)."""
+        bsize_list, stream = _np(bsize_list, I32), _np(b_colidx_orig, I32)
+        b = bsize_list.size - 1
+        local, keys, off, nk = np.empty(R.nnz, I32), np.empty(R.nnz, I32), np.empty(b + 1, I32), C.c_int32()
+        _chk(lib().spmm_first_touch(self._h, C.c_int32(R.nrow), C.c_int32(R.ncol), C.c_int32(R.nnz), _p(R.indptr),
+                                    _p(bsize_list), C.c_int32(b), _p(stream), _p(local), _p(keys), C.byref(nk), _p(off)))
+        return local, keys[:nk.value].copy(), off
+
+    def wbseq(self, nrow, seq_bitmap, out_seq_all, bsize_list, keys):
+        """a9 (wbsort.h:58-67, 16-34, 81-95) -> (seq_input, rseq)."""
+        seq_bitmap, out_seq_all, bsize_list, keys = (_np(x, I32) for x in (seq_bitmap, out_seq_all, bsize_list, keys))
+        seq_input, rseq = np.empty(keys.size, I32), np.empty(nrow, I32)
+        _chk(lib().spmm_wbseq(self._h, C.c_int32(nrow), _p(seq_bitmap), _p(out_seq_all), _p(bsize_list),
+                              C.c_int32(bsize_list.size - 1), _p(keys), C.c_int32(keys.size), _p(seq_input), _p(rseq)))
+        return seq_input, rseq
+
     # ---- product -------------------------------------------------------------
     def spgemm_symbolic(self, A, B=None):
         B = A if B is None else B

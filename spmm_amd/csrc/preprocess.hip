@@ -688,3 +688,173 @@ extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect
     ctx->last_ms = ms;
     return SPMM_OK;
 }
+
+// ===========================================================================
+// C ABI: the stages one by one with host arrays
+namespace {
+template <typename T>
+int h2d_new(spmm_ctx* ctx, std::vector<void*>& pool, const T* host, size_t count, T** dev) {
+    CHK(dalloc(pool, count, dev));
+    if (count) HIPCHK(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return SPMM_OK;
+}
+int check_host_csr(const spmm_csr* M) {
+    ARGCHK(M != nullptr && M->nrow >= 0 && M->ncol >= 0 && M->nnz >= 0 && M->indptr != nullptr);
+    ARGCHK(M->nnz == 0 || (M->indices != nullptr && M->data != nullptr));
+    return SPMM_OK;
+}
+int finish_timed(spmm_ctx* ctx) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->last_ms = ms;
+    return SPMM_OK;
+}
+}  // namespace
+
+extern "C" int spmm_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* seq, int32_t* r_indptr,
+                                   int32_t* r_indices, double* r_data) {
+    ARGCHK(ctx != nullptr && seq != nullptr && r_indptr != nullptr && sect > 0);
+    CHK(check_host_csr(A));
+    ARGCHK(A->nnz == 0 || (r_indices != nullptr && r_data != nullptr));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)A->nrow, z = (size_t)A->nnz;
+    PoolGuard g;
+    int32_t *a_ip, *a_ix, *d_seq, *r_ip, *r_ix;
+    double *a_val, *r_val;
+    CHK(h2d_new(ctx, g.pool, A->indptr, n + 1, &a_ip));
+    CHK(h2d_new(ctx, g.pool, A->indices, z, &a_ix));
+    CHK(h2d_new(ctx, g.pool, A->data, z, &a_val));
+    spmm_csr dA = *A;
+    dA.indptr = a_ip; dA.indices = a_ix; dA.data = a_val;
+    CHK(dalloc(g.pool, n, &d_seq));
+    CHK(dalloc(g.pool, n + 1, &r_ip));
+    CHK(dalloc(g.pool, z, &r_ix));
+    CHK(dalloc(g.pool, z, &r_val));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    CHK(dev_bitmap_reorder(ctx, &dA, sect, d_seq, r_ip, r_ix, r_val));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    CHK(d2h(ctx, seq, d_seq, n));
+    CHK(d2h(ctx, r_indptr, r_ip, n + 1));
+    CHK(d2h(ctx, r_indices, r_ix, z));
+    CHK(d2h(ctx, r_data, r_val, z));
+    return finish_timed(ctx);
+}
+
+extern "C" int spmm_gen_blocks(spmm_ctx* ctx, const spmm_csr* R, int32_t threshold, int32_t* bsize_list, int32_t cap,
+                               int32_t* bnum) {
+    ARGCHK(ctx != nullptr && bsize_list != nullptr && bnum != nullptr && threshold > 0 && cap >= 2);
+    CHK(check_host_csr(R));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)R->nrow, z = (size_t)R->nnz;
+    PoolGuard g;
+    int32_t *r_ip, *r_ix, *bsize;
+    CHK(h2d_new(ctx, g.pool, R->indptr, n + 1, &r_ip));
+    CHK(h2d_new(ctx, g.pool, R->indices, z, &r_ix));
+    CHK(dalloc(g.pool, (size_t)cap, &bsize));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    CHK(dev_gen_blocks(ctx, R->nrow, R->ncol, R->nnz, r_ip, r_ix, threshold, bsize, cap, bnum));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    CHK(d2h(ctx, bsize_list, bsize, (size_t)*bnum + 1));
+    return finish_timed(ctx);
+}
+
+extern "C" int spmm_panels_sort_pack(spmm_ctx* ctx, const spmm_csr* R, const int32_t* bsize_list, int32_t bnum,
+                                     int32_t* panel_ptr, int32_t* panel_list, int32_t* n_panel_entries, int32_t* spv8_list,
+                                     int32_t* n_spv8, int32_t* out_seq_all, int32_t* b_indptr, int32_t* b_colidx_orig,
+                                     double* b_data) {
+    ARGCHK(ctx != nullptr && bsize_list != nullptr && bnum >= 1);
+    CHK(check_host_csr(R));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)R->nrow, z = (size_t)R->nnz;
+    PoolGuard g;
+    int32_t *r_ip, *r_ix, *bsize;
+    double* r_val;
+    CHK(h2d_new(ctx, g.pool, R->indptr, n + 1, &r_ip));
+    CHK(h2d_new(ctx, g.pool, R->indices, z, &r_ix));
+    CHK(h2d_new(ctx, g.pool, R->data, z, &r_val));
+    CHK(h2d_new(ctx, g.pool, bsize_list, (size_t)bnum + 1, &bsize));
+    PanelsDev P;
+    int8_t* grp;
+    int32_t *perm2, *g_ip, *d_bip, *d_bix;
+    double* d_bval;
+    CHK(dalloc(g.pool, (size_t)bnum + 1, &P.panel_ptr));
+    CHK(dalloc(g.pool, n / 8 + 3 * (size_t)bnum + 8, &P.panel_list));
+    CHK(dalloc(g.pool, n / 8 + 3 * (size_t)bnum + 8, &P.spv8));
+    CHK(dalloc(g.pool, n, &P.out_seq));
+    CHK(dalloc(g.pool, n, &grp));
+    P.grp = grp;
+    CHK(dalloc(g.pool, n, &perm2));
+    CHK(dalloc(g.pool, n + 1, &g_ip));
+    CHK(dalloc(g.pool, n + (size_t)bnum, &d_bip));
+    CHK(dalloc(g.pool, z, &d_bix));
+    CHK(dalloc(g.pool, z, &d_bval));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    CHK(dev_panels(ctx, R->nrow, bnum, bsize, r_ip, &P));
+    CHK(dev_pack(ctx, R->nrow, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, d_bip, d_bix, d_bval));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (n_panel_entries) *n_panel_entries = P.n_list;
+    if (n_spv8) *n_spv8 = P.npanel;
+    CHK(d2h(ctx, panel_ptr, P.panel_ptr, (size_t)bnum + 1));
+    CHK(d2h(ctx, panel_list, P.panel_list, (size_t)P.n_list));
+    CHK(d2h(ctx, spv8_list, P.spv8, (size_t)P.npanel));
+    CHK(d2h(ctx, out_seq_all, P.out_seq, n));
+    CHK(d2h(ctx, b_indptr, d_bip, n + (size_t)bnum));
+    CHK(d2h(ctx, b_colidx_orig, d_bix, z));
+    CHK(d2h(ctx, b_data, d_bval, z));
+    return finish_timed(ctx);
+}
+
+extern "C" int spmm_first_touch(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* r_indptr,
+                                const int32_t* bsize_list, int32_t bnum, const int32_t* b_colidx_orig, int32_t* b_local,
+                                int32_t* keys, int32_t* n_keys, int32_t* seq_offset) {
+    ARGCHK(ctx != nullptr && nrow >= 0 && ncol >= 0 && nnz >= 0 && bnum >= 1);
+    ARGCHK(r_indptr != nullptr && bsize_list != nullptr && n_keys != nullptr && (nnz == 0 || b_colidx_orig != nullptr));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)nrow, z = (size_t)nnz;
+    PoolGuard g;
+    int32_t *r_ip, *bsize, *stream, *d_local, *d_keys, *d_off;
+    CHK(h2d_new(ctx, g.pool, r_indptr, n + 1, &r_ip));
+    CHK(h2d_new(ctx, g.pool, bsize_list, (size_t)bnum + 1, &bsize));
+    CHK(h2d_new(ctx, g.pool, b_colidx_orig, z, &stream));
+    CHK(dalloc(g.pool, z, &d_local));
+    CHK(dalloc(g.pool, z, &d_keys));
+    CHK(dalloc(g.pool, (size_t)bnum + 1, &d_off));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    CHK(dev_first_touch(ctx, ncol, nnz, bnum, bsize, r_ip, stream, d_local, d_keys, d_off, n_keys));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    CHK(d2h(ctx, b_local, d_local, z));
+    CHK(d2h(ctx, keys, d_keys, (size_t)*n_keys));
+    CHK(d2h(ctx, seq_offset, d_off, (size_t)bnum + 1));
+    return finish_timed(ctx);
+}
+
+extern "C" int spmm_wbseq(spmm_ctx* ctx, int32_t nrow, const int32_t* seq_bitmap, const int32_t* out_seq_all,
+                          const int32_t* bsize_list, int32_t bnum, const int32_t* keys, int32_t n_keys, int32_t* seq_input,
+                          int32_t* rseq) {
+    ARGCHK(ctx != nullptr && nrow >= 0 && bnum >= 1 && n_keys >= 0);
+    ARGCHK(seq_bitmap != nullptr && out_seq_all != nullptr && bsize_list != nullptr && (n_keys == 0 || keys != nullptr));
+    for (int32_t i = 0; i < n_keys; i++)
+        if ((uint32_t)keys[i] >= (uint32_t)nrow) {
+            spmm_set_error("wbseq: key %d at %d is not a row id (the write-back sequence needs ncol <= nrow)", keys[i], i);
+            return SPMM_E_ARG;
+        }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)nrow;
+    PoolGuard g;
+    int32_t *d_seq, *d_out, *bsize, *d_keys, *perm2, *d_in, *d_rseq;
+    CHK(h2d_new(ctx, g.pool, seq_bitmap, n, &d_seq));
+    CHK(h2d_new(ctx, g.pool, out_seq_all, n, &d_out));
+    CHK(h2d_new(ctx, g.pool, bsize_list, (size_t)bnum + 1, &bsize));
+    CHK(h2d_new(ctx, g.pool, keys, (size_t)n_keys, &d_keys));
+    CHK(dalloc(g.pool, n, &perm2));
+    CHK(dalloc(g.pool, (size_t)n_keys, &d_in));
+    CHK(dalloc(g.pool, n, &d_rseq));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (nrow > 0) hipLaunchKernelGGL(k_perm2, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, d_out, bsize, bnum, perm2);
+    CHK(dev_wbseq(ctx, nrow, d_seq, perm2, d_keys, n_keys, d_in, d_rseq));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    CHK(d2h(ctx, seq_input, d_in, (size_t)n_keys));
+    CHK(d2h(ctx, rseq, d_rseq, n));
+    return finish_timed(ctx);
+}

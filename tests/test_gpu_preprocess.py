@@ -91,3 +91,41 @@ def test_pipeline_block_capacity_is_an_error(ctx):
     with pytest.raises(capi.SpmmError) as e:
         ctx.trace_formats(capi.Csr(n, n, ip, ix, d), threshold=64, cap_blocks=5)
     assert e.value.code == -3
+
+
+@pytest.mark.parametrize("threshold,sect", [(500, 16), (65536, 2048)])
+def test_stage_entry_points_chain_to_the_pipeline(ctx, threshold, sect):
+    """The five stage calls, chained through host arrays, give what spmm_trace_formats gives, and
+    each stage equals the oracle's function for that stage."""
+    n = 1 << 13
+    row, col = synth.rmat(13, 8, 21, True)
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    d = np.random.default_rng(2).integers(1, 9, d.size).astype(np.float64)
+    A = capi.Csr(n, n, ip, ix, d)
+    full = ctx.trace_formats(A, sect=sect, threshold=threshold)
+
+    seq, R = ctx.bitmap_reorder(A, sect)
+    o_ip, o_ix, o_d, o_seq = orc.bitmap_reorder(n, ip, ix, d, sect)
+    assert np.array_equal(seq, o_seq) and np.array_equal(R.indptr, o_ip) and np.array_equal(R.indices, o_ix)
+    assert np.array_equal(R.data, o_d) and ctx.last_kernel_ms() > 0
+
+    bsize = ctx.gen_blocks(R, threshold)
+    assert np.array_equal(bsize, orc.gen_blocks(n, R.indptr, R.indices, threshold))
+    with pytest.raises(capi.SpmmError) as e:
+        ctx.gen_blocks(R, threshold=8, cap=3)               # more blocks than the list holds
+    assert e.value.code == -3
+
+    P = ctx.panels_sort_pack(R, bsize)
+    for k in ("panel_ptr", "panel_list", "spv8_list", "out_seq_all", "b_indptr", "b_colidx_orig", "b_data"):
+        assert np.array_equal(P[k], full[k]), k
+
+    local, keys, off = ctx.first_touch(R, bsize, P["b_colidx_orig"])
+    assert np.array_equal(local, full["b_local"]) and np.array_equal(keys, full["keys"])
+    assert np.array_equal(off, full["seq_offset"])
+
+    seq_input, rseq = ctx.wbseq(n, seq, P["out_seq_all"], bsize, keys)
+    assert np.array_equal(seq_input, full["seq_input"]) and np.array_equal(rseq, full["rseq"])
+    o_in, o_rseq = orc.wbseq(seq, P["out_seq_all"], bsize, keys)
+    assert np.array_equal(seq_input, o_in) and np.array_equal(rseq, o_rseq)
+    with pytest.raises(capi.SpmmError):
+        ctx.wbseq(n, seq, P["out_seq_all"], bsize, np.array([n + 5], np.int32))    # a key that is no row id
