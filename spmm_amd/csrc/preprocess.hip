@@ -42,20 +42,38 @@ __device__ __forceinline__ int last_le(const int32_t* __restrict__ a, int n, int
 // ---------------------------------------------------------------------------
 // Row key, bitmap.h:123-143: walk the row, sec = col / sect; when the section rises above the
 // previous element's and the running score beats the best, the PREVIOUS section becomes the
-// best and the score restarts (only then); key = best section + 1.  One thread per row.
+// best and the score restarts (only then); key = best section + 1.  One wave per row: the lanes
+// read 64 elements at a time and find the places where the section rises; the state machine
+// only runs over those (at most ncol / sect per row), so a hub row of 10^5 entries costs a
+// few thousand wave instructions instead of 10^5 dependent loads.
 __global__ void __launch_bounds__(256) k_row_keys(int32_t nrow, const int32_t* __restrict__ ip,
                                                   const int32_t* __restrict__ ix, int32_t sect,
                                                   uint32_t* __restrict__ keys) {
-    GRID_STRIDE(r, nrow) {
-        int best = 0, best_sec = -1, prev_sec = 0, score = 0;
-        const int e = ip[r + 1];
-        for (int p = ip[r]; p < e; p++) {
-            int sec = ix[p] / sect;
-            if (sec > prev_sec && score > best) { best = score; best_sec = prev_sec; score = 0; }
-            prev_sec = sec;
-            score++;
+    const int lane = threadIdx.x & 63;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrow; r += nwave) {
+        int best = 0, best_sec = -1, prev_sec = 0, score = 0;   // wave-uniform
+        const int b = ip[r], e = ip[r + 1];
+        for (int p0 = b; p0 < e; p0 += 64) {
+            const int p = p0 + lane;
+            const bool valid = p < e;
+            const int sec = valid ? ix[p] / sect : 0;
+            int before = __shfl_up(sec, 1, 64);
+            if (lane == 0) before = prev_sec;
+            unsigned long long rise = __ballot(valid && sec > before);
+            const int nvalid = e - p0 < 64 ? e - p0 : 64;
+            int last = 0;                                     // elements of this chunk already counted
+            while (rise) {
+                const int at = __ffsll(rise) - 1;
+                rise &= rise - 1;
+                score += at - last;                           // elements of the previous section
+                last = at;
+                if (score > best) { best = score; best_sec = __builtin_amdgcn_readlane(before, at); score = 0; }
+            }
+            score += nvalid - last;
+            prev_sec = __builtin_amdgcn_readlane(sec, nvalid - 1);
         }
-        keys[r] = (uint32_t)(best_sec + 1);
+        if (lane == 0) keys[r] = (uint32_t)(best_sec + 1);
     }
 }
 
@@ -122,61 +140,105 @@ __global__ void k_prev_from_sorted(int64_t n, const uint32_t* __restrict__ col_s
     }
 }
 
-// Greedy blocking, transmat.h:346-362, as one workgroup walking the stream: an element is a new
-// column of the block that starts at stream position s0 iff prev < s0; the block is cut after the
-// row that holds the threshold-th new column.  8192 elements per step.
-constexpr int BC_THREADS = 1024, BC_ITEMS = 8;
-__global__ void __launch_bounds__(BC_THREADS) k_block_chain(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
-                                                            const int32_t* __restrict__ prev, int32_t threshold,
-                                                            int32_t* __restrict__ bsize, int32_t cap,
-                                                            int32_t* __restrict__ result /* [0]=bnum or -1 */) {
-    __shared__ int32_t tmp[BC_THREADS / 64 + 1];
-    __shared__ int32_t cut_pos;
-    const int tid = threadIdx.x;
-    int nb = 1;          // entries written (bsize[0] = 0)
-    if (tid == 0) bsize[0] = 0;
-    int s0 = 0, cnt = 0, p = 0;
-    bool overflow = cap < 2;
-    while (!overflow && p < nnz) {
-        unsigned mask = 0;
-        const int q0 = p + tid * BC_ITEMS;
-#pragma unroll
-        for (int j = 0; j < BC_ITEMS; j++) {
-            int q = q0 + j;
-            if (q < nnz && prev[q] < s0) mask |= 1u << j;
-        }
-        const int c = __popc(mask);
-        int tot;
-        const int ex = block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
-        if (cnt + tot < threshold) {
-            cnt += tot;
-            p += BC_THREADS * BC_ITEMS;
-            continue;
-        }
-        const int target = threshold - cnt;   // 1-based rank of the deciding element in this step
-        if (ex < target && target <= ex + c) {
-            unsigned m = mask;
-            for (int k = target - ex; k > 1; k--) m &= m - 1u;
-            cut_pos = q0 + (__ffs(m) - 1);
-        }
-        __syncthreads();
-        const int r = last_le(r_ip, nrow + 1, cut_pos);   // row holding that element
-        if (nb + 1 >= cap) { overflow = true; break; }
-        if (tid == 0) bsize[nb] = r + 1;
-        nb++;
-        s0 = r_ip[r + 1];
-        cnt = 0;
-        p = s0;
-        __syncthreads();
+// Greedy blocking, transmat.h:346-362: an element is a new column of the block that starts at
+// stream position s0 iff prev < s0; the block is cut after the row that holds the threshold-th
+// new column.  The chain of cuts is serial, the counting is not: one launch = one step of the
+// chain.  BC_TILES workgroups count the new columns of 8192 elements each from the current
+// position; the workgroup that finishes last adds the tile counts, finds the deciding tile and
+// element, cuts, and moves the state on.  Steps after the end of the stream do nothing.
+constexpr int BC_THREADS = 1024, BC_ITEMS = 8, BC_TILE = BC_THREADS * BC_ITEMS, BC_TILES = 64;
+struct bc_state {
+    int32_t s0, pos, cnt, nb, done, overflow, ticket, pad;
+    int32_t tile_cnt[BC_TILES];
+};
+
+__global__ void k_block_chain_init(bc_state* st, int32_t* __restrict__ bsize, int32_t cap) {
+    if (threadIdx.x == 0) {
+        st->s0 = st->pos = st->cnt = 0;
+        st->nb = 1;
+        st->done = 0;
+        st->overflow = cap < 2 ? 1 : 0;
+        st->ticket = 0;
+        if (cap >= 1) bsize[0] = 0;
     }
-    if (!overflow && nb >= cap) overflow = true;
-    if (tid == 0) {
-        if (overflow) {
-            result[0] = -1;
-        } else {
-            bsize[nb] = nrow;
-            result[0] = nb;   // bnum = entries - 1 = nb
+}
+
+__global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
+                                                                 const int32_t* __restrict__ prev, int32_t threshold,
+                                                                 int32_t* __restrict__ bsize, int32_t cap, bc_state* st) {
+    __shared__ int32_t tmp[BC_THREADS / 64 + 1];
+    __shared__ int32_t sh_last, sh_cut;
+    const int tid = threadIdx.x;
+    if (st->done || st->overflow) return;          // written only by the last workgroup of an earlier launch
+    const int s0 = st->s0, pos = st->pos;
+    {
+        const int q0 = pos + (int)blockIdx.x * BC_TILE + tid * BC_ITEMS;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < BC_ITEMS; j++) c += (q0 + j < nnz && prev[q0 + j] < s0) ? 1 : 0;
+        int tot;
+        block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
+        if (tid == 0) {
+            st->tile_cnt[blockIdx.x] = tot;
+            __threadfence();
+            sh_last = atomicAdd(&st->ticket, 1) == BC_TILES - 1 ? 1 : 0;
         }
+        __syncthreads();
+        if (!sh_last) return;
+        __threadfence();
+    }
+    // ---- the last workgroup of the step decides -----------------------------------
+    int cnt = st->cnt, run = 0, hit = -1;
+    for (int t = 0; t < BC_TILES; t++) {           // uniform: every thread reads the same 64 counts
+        const int c = ((volatile int32_t*)st->tile_cnt)[t];
+        if (hit < 0 && cnt + run + c >= threshold) { hit = t; break; }
+        run += c;
+    }
+    if (hit < 0) {
+        if (tid == 0) {
+            st->cnt = cnt + run;
+            st->pos = pos + BC_TILES * BC_TILE;
+            st->ticket = 0;
+            if (pos + BC_TILES * BC_TILE >= nnz) {                 // end of the stream: the last block takes the rest
+                if (st->nb >= cap) st->overflow = 1; else bsize[st->nb] = nrow;
+                st->done = 1;
+            }
+        }
+        return;
+    }
+    // the deciding element is the target-th new column of tile `hit`
+    const int target = threshold - cnt - run;
+    const int q0 = pos + hit * BC_TILE + tid * BC_ITEMS;
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < BC_ITEMS; j++)
+        if (q0 + j < nnz && prev[q0 + j] < s0) mask |= 1u << j;
+    const int c = __popc(mask);
+    int tot;
+    const int ex = block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
+    if (ex < target && target <= ex + c) {
+        unsigned m = mask;
+        for (int k = target - ex; k > 1; k--) m &= m - 1u;
+        sh_cut = q0 + (__ffs(m) - 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int r = last_le(r_ip, nrow + 1, sh_cut);             // row holding that element
+        const int nb = st->nb;
+        if (nb + 1 >= cap) {
+            st->overflow = 1;
+        } else {
+            bsize[nb] = r + 1;
+            st->nb = nb + 1;
+            const int ns = r_ip[r + 1];
+            st->s0 = st->pos = ns;
+            st->cnt = 0;
+            if (ns >= nnz) {                                       // the stream ends with this cut
+                if (nb + 1 >= cap) st->overflow = 1; else bsize[nb + 1] = nrow;
+                st->done = 1;
+            }
+        }
+        st->ticket = 0;
     }
 }
 
@@ -423,7 +485,7 @@ int dev_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* 
     CHK(ws(ctx, WS_RADIX_V0, (size_t)n + 1, &v0));
     CHK(ws(ctx, WS_RADIX_K1, (size_t)n + 1, &k1));
     if (n > 0) {
-        hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, k0);
+        hipLaunchKernelGGL(k_row_keys, dim3(grid_for(((int64_t)n + 3) / 4 * 256, 256, 256 * 64)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, k0);
         hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)n);
         CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, (uint32_t*)seq, n, bits_for((uint32_t)(A->ncol / sect))));
     }
@@ -438,20 +500,36 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
     int ph = phase_begin(ctx, SPMM_PH_BLOCKS);
     uint32_t *cs, *psd;
     CHK(sort_stream_by_col(ctx, r_ix, nnz, ncol, &cs, &psd));
-    int32_t *prev, *result;
+    int32_t* prev;
+    bc_state* st;
     CHK(ws(ctx, WS_MISC1, (size_t)nnz + 1, &prev));
-    CHK(ws(ctx, WS_COUNTERS, 64, &result));
+    CHK(ws(ctx, WS_COUNTERS, sizeof(bc_state) / sizeof(int32_t) + 1, (int32_t**)&st));
     if (nnz > 0)
         hipLaunchKernelGGL(k_prev_from_sorted, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, prev);
-    hipLaunchKernelGGL(k_block_chain, dim3(1), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, prev, threshold, bsize, cap, result);
+    hipLaunchKernelGGL(k_block_chain_init, dim3(1), dim3(64), 0, ctx->stream, st, bsize, cap);
+    // one launch per step of the chain; the number of steps (blocks + windows without a cut) is only
+    // known on the device, so steps are queued in batches and the state is read back after each
     int32_t* h = (int32_t*)ctx->pinned;
-    HIPCHK(hipMemcpyAsync(h, result, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // every step either cuts a block (at most nrow of them) or moves on by BC_TILES tiles
+    const int64_t max_steps = (int64_t)nrow + (int64_t)nnz / (BC_TILES * BC_TILE) + 2;
+    for (int64_t steps = 0;; steps += 128) {
+        if (steps > max_steps + 128) {
+            spmm_set_error("gen_blocks: the block chain did not finish in %lld steps", (long long)max_steps);
+            return SPMM_E_HIP;
+        }
+        for (int i = 0; i < 128; i++)
+            hipLaunchKernelGGL(k_block_chain_step, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, prev,
+                               threshold, bsize, cap, st);
+        HIPCHK(hipMemcpyAsync(h, st, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (h[4] || h[5]) break;   // done or overflow
+    }
     phase_end(ctx, ph);
-    if (h[0] < 0) {
+    if (h[5]) {
         spmm_set_error("gen_blocks: more than %d blocks; the block list is too small", cap - 1);
         return SPMM_E_CAPACITY;
     }
+    h[0] = h[3];
     *bnum_host = h[0];
     return SPMM_OK;
 }

@@ -27,10 +27,14 @@ def main():
         ctx.csr_from_coo(n, n, row, col)
         csr_ms = ctx.last_kernel_ms()
         ctx.trace_formats(A)
+        ctx.profile(True)
         t0 = time.perf_counter()
         g = ctx.trace_formats(A)
         wall_ms = (time.perf_counter() - t0) * 1e3
         gpu_ms = ctx.last_kernel_ms()
+        stages = {name: round(ctx.phase_ms(pid)[0], 3) for name, pid in
+                  [("reorder", 7), ("blocks", 8), ("panels", 9), ("pack", 10), ("renumber", 11), ("wbseq", 12)]}
+        ctx.profile(False)
         t0 = time.perf_counter()
         o = orc.trace_formats(n, ip, ix, d, sort_mode=1)
         cpu_ms = (time.perf_counter() - t0) * 1e3
@@ -38,7 +42,7 @@ def main():
         out = dict(case=f"R-MAT scale {scale} edge factor 16 seed 7 with diagonal", rows=n, nnz=int(ix.size),
                    blocks=int(g["bnum"]), gpu_csr_build_kernel_ms=round(csr_ms, 3), gpu_trace_formats_kernel_ms=round(gpu_ms, 3),
                    gpu_trace_formats_wall_ms_with_pcie=round(wall_ms, 1), cpu_oracle_ms=round(cpu_ms, 1),
-                   gpu_equals_oracle=bool(same))
+                   gpu_equals_oracle=bool(same), gpu_stage_ms=stages)
         if ref.available():
             ref.set_csr(n, ip, ix, d)
             t0 = time.perf_counter()
