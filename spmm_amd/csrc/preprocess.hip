@@ -188,12 +188,26 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
         __threadfence();
     }
     // ---- the last workgroup of the step decides -----------------------------------
-    int cnt = st->cnt, run = 0, hit = -1;
-    for (int t = 0; t < BC_TILES; t++) {           // uniform: every thread reads the same 64 counts
-        const int c = ((volatile int32_t*)st->tile_cnt)[t];
-        if (hit < 0 && cnt + run + c >= threshold) { hit = t; break; }
-        run += c;
+    static_assert(BC_TILES == 64, "one lane per tile count");
+    const int cnt = st->cnt;
+    if (tid < 64) {                                // inclusive sums of the tile counts across the first wave
+        const int c = ((volatile int32_t*)st->tile_cnt)[tid];
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            inc += tid >= d ? o : 0;
+        }
+        const unsigned long long reach = __ballot(cnt + inc >= threshold);
+        const int first = reach ? __ffsll(reach) - 1 : -1;
+        if (tid == (first < 0 ? 63 : first)) {
+            sh_last = first;                       // deciding tile, or -1
+            sh_cut = first < 0 ? inc : inc - c;    // new columns of the tiles before it (all tiles when none decides)
+        }
     }
+    __syncthreads();
+    const int hit = sh_last, run = sh_cut;
+    __syncthreads();
     if (hit < 0) {
         if (tid == 0) {
             st->cnt = cnt + run;
@@ -222,8 +236,21 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
         sh_cut = q0 + (__ffs(m) - 1);
     }
     __syncthreads();
+    // row holding that element: 1024-way search over the row pointers, all threads
+    int lo = 0, hi = nrow + 1;
+    {
+        const int v = sh_cut;
+        while (hi - lo > 1) {
+            const int step = (hi - lo + BC_THREADS - 1) / BC_THREADS;
+            const int idx = lo + tid * step;
+            const int c = __syncthreads_count(idx < hi && r_ip[idx] <= v);   // true for threads 0..c-1
+            const int nlo = lo + (c - 1) * step;
+            hi = lo + c * step < hi ? lo + c * step : hi;
+            lo = nlo;
+        }
+    }
     if (tid == 0) {
-        const int r = last_le(r_ip, nrow + 1, sh_cut);             // row holding that element
+        const int r = lo;
         const int nb = st->nb;
         if (nb + 1 >= cap) {
             st->overflow = 1;
