@@ -1218,6 +1218,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* bits = (uint32_t*)smem;
     int32_t* tmp = (int32_t*)(bits + WORDS);
+    uint8_t* wmap = (uint8_t*)(tmp + 4) + (threadIdx.x >> 6) * 256;   // 256 bytes per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = list[blockIdx.x];
@@ -1254,32 +1255,10 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
                 if (v1) sym_mark(bits, q1, cbase);
             }
             const int rem = lane < E ? len - 2 * LA : 0;
-            unsigned long long mask_c = __ballot(rem > 128);
-            unsigned long long mask_b = __ballot(rem > 0 && rem <= 128);
-            // tier 2: 16 lanes per entry, four entries at a time
-            const int nb = __popcll(mask_b);
-            const int g = lane >> 4, sl = lane & 15;
-            for (int it = 0; it < nb; it += 4) {
-                int l4[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    l4[q] = mask_b ? __ffsll(mask_b) - 1 : 0;
-                    mask_b &= mask_b - 1;
-                }
-                const int src = g == 0 ? l4[0] : g == 1 ? l4[1] : g == 2 ? l4[2] : l4[3];
-                // every lane takes part in the shuffles: a masked-off source lane would read as 0
-                const int ss = __shfl(s, src, 64) + 2 * LA;
-                const int rsrc = __shfl(rem, src, 64);
-                const int rr = it + g < nb ? rsrc : 0;
-                for (int i = sl; i < rr; i += 64) {
-                    int cq[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) cq[q] = i + 16 * q < rr ? b_ix[ss + i + 16 * q] : -1;
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (i + 16 * q < rr) sym_mark(bits, cq[q], cbase);
-                }
-            }
+            unsigned long long mask_c = __ballot(rem > 256);
+            // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
+            wave_flat_sweep<false>(b_ix, nullptr, s + 2 * LA, rem <= 256 ? rem : 0, 0.0, lane, wmap,
+                                   [&](int col, double) { sym_mark(bits, col, cbase); });
             // tier 3: the whole wave on one entry
             while (mask_c) {
                 const int src = __ffsll(mask_c) - 1;
@@ -1313,7 +1292,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
     if (tid == 0) rowcnt[row] = tmp[0];
 }
 
-constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16; }
+constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16 + 16 * 256; }
 
 constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * (8 + 256); }
 
