@@ -5,19 +5,21 @@
 //
 // Rows are binned by their number of intermediate products P_i = sum_k len_B(k):
 //   P_i == 0                 nothing to do
-//   P_i <= ESC_S_CAP (512)   one 64-lane workgroup: expand the products into LDS, bitonic sort
-//                            by column, sum runs of equal columns
-//   P_i <= ESC_L_CAP (4096)  the same with a 256-thread workgroup
-//   larger                   "window" rows, one 1024-thread workgroup per row, heaviest first.
-//                            The column range is cut into windows that fit an LDS bitmap; a
-//                            sweep over the row's B segments sets one bit per touched column,
-//                            a popcount prefix over the bitmap words ranks the columns (sorted
-//                            output for free), and a second sweep adds the products into a
-//                            compact fp64 array indexed by rank with LDS atomics.  A window
-//                            holding more distinct columns than the fp64 array is finished in
-//                            several value sweeps over the same bitmap.  Every A entry keeps a
-//                            cursor into its B row (B rows are sorted), so each sweep touches
-//                            only the products of its window.
+//   P_i <= ESC_S_CAP (512)   k_esc: one 64-lane workgroup expands the products into LDS, bitonic
+//                            sort by column, runs of equal columns summed
+//   P_i <= ESC_R_CAP (8192)  k_escr: expand (column, index) pairs, stable LSD radix sort in LDS,
+//                            runs summed in product order; independent of the column span
+//   larger                   "window" rows, one 1024-thread workgroup per row, heaviest first,
+//                            over the window-pointer table of B (k_winptr): T[k][w] = first
+//                            position of B row k with column >= w << shift, so the part of a B
+//                            row inside a column window costs two loads and no search.
+//       symbolic             k_symd: LDS bitmap of 2^20 columns, one ds_or per product
+//       numeric, P_i >= dense_min (2^18)
+//                            k_dense: dense fp64 accumulators for 2^14 columns + flag bytes
+//       numeric, below       k_win: bitmap + popcount rank prefix + compact fp64 accumulators
+//                            per window of up to 2^18 columns; windows of at most 8192 products
+//                            stay in registers between the bit sweep and the value phase
+//   The output rows are sorted by column in every bin; global-memory accumulation is never used.
 #include "common.h"
 
 namespace {
