@@ -78,13 +78,41 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Rehearsal of the multi-rank path on a box with one GPU: SPMM_BENCH_REHEARSE=1 puts every rank on
+    # cuda:0 and runs the collectives over gloo with host staging.  Numbers of such a run mean nothing.
+    rehearse = os.environ.get("SPMM_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
-        import torch.distributed as dist
+        import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            tdist.init_process_group("gloo")
+
+            class _HostStaged:
+                ReduceOp = tdist.ReduceOp
+                barrier = staticmethod(tdist.barrier)
+                destroy_process_group = staticmethod(tdist.destroy_process_group)
+
+                @staticmethod
+                def all_gather_into_tensor(out, inp):
+                    o = torch.empty(out.shape, dtype=out.dtype)
+                    tdist.all_gather_into_tensor(o, inp.cpu())
+                    out.copy_(o)
+
+                @staticmethod
+                def all_reduce(t, op):
+                    h = t.cpu()
+                    tdist.all_reduce(h, op=op)
+                    t.copy_(h)
+
+            dist = _HostStaged
+        else:
+            tdist.init_process_group("nccl", device_id=dev)
+            dist = tdist
 
     ctx = capi.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -118,9 +146,11 @@ def main():
     vB = capi.dev_view(n, n, nnz, indptr, indices, data)
     prod = torch.empty(n, dtype=torch.int64, device=dev)
     P_total = ctx.row_products_dev(vB, vB, prod)
-    # rows of A per rank: equal shares of the intermediate products
+    # rows of A per rank: equal shares of the intermediate products, weighted by the kernel class of the row
     cum = torch.cumsum(prod, 0)
-    bounds = shard.product_balanced_bounds(prod, world)
+    _, esc_max = capi.bin_limits()
+    _, _, dense_min_products = ctx.plan_info(n)
+    bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min_products)
     r_lo, r_hi = bounds[rank], bounds[rank + 1]
     rows_l = r_hi - r_lo
     P_local = int(prod[r_lo:r_hi].sum())
@@ -289,7 +319,7 @@ def main():
                warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=workload,
-                           rows=n, nnz=nnz, products=P_total, nnz_c=nnz_c_total, partition="rows of A by product count",
+                           rows=n, nnz=nnz, products=P_total, nnz_c=nnz_c_total, partition="rows of A by product count weighted by kernel class",
                            step="symbolic+numeric", c_row_blocks_per_step=state["blocks"], rank0_rows=rows_l,
                            b_allgather_ms=round(b_allgather_ms, 3), setup_s=round(setup_s, 1)),
                phases_ms_per_step={k: round(v[0] / args.steps, 3) for k, v in ph.items()},

@@ -57,3 +57,33 @@ def product_balanced_bounds(prod, world):
         bounds.append(max(bounds[-1], min(b, n)))
     bounds.append(n)
     return bounds
+
+
+# Measured cost of one intermediate product by the kernel class of its row (ns per product on one
+# MI355X at R-MAT scale 22, symbolic + numeric): the dense-accumulator rows run at ~85 products/ns,
+# the window rows below them at ~63, the expand-sort-compress rows at ~34; the symbolic pass adds
+# ~1/500 for window rows and ~1/72 for the sorted rows.  Only the ratios matter.
+COST_NS = {"dense": 1 / 85 + 1 / 500, "window": 1 / 63 + 1 / 500, "sorted": 1 / 34 + 1 / 72}
+
+
+def cost_balanced_bounds(prod, world, sorted_max, dense_min):
+    """Row boundaries like product_balanced_bounds, with every row's products weighted by the cost
+    of its kernel class (rows with at most sorted_max products are sorted, rows with at least
+    dense_min use dense accumulators), so that the ranks finish together and not merely hold the
+    same number of products."""
+    n = prod.numel()
+    if n == 0:
+        return [0] * (world + 1)
+    p = prod.to(torch.float64)
+    w = torch.full_like(p, COST_NS["window"])
+    w[prod <= sorted_max] = COST_NS["sorted"]
+    w[prod >= dense_min] = COST_NS["dense"]
+    cum = torch.cumsum(p * w, 0)
+    total = float(cum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        target = torch.tensor([total * r / world], dtype=torch.float64, device=prod.device)
+        b = int(torch.searchsorted(cum, target)[0])
+        bounds.append(max(bounds[-1], min(b, n)))
+    bounds.append(n)
+    return bounds

@@ -84,3 +84,15 @@ def test_bounds_edge_cases():
     b = shard.product_balanced_bounds(torch.tensor([0, 0, 100, 0], dtype=torch.int64), 2)
     assert b[0] == 0 and b[-1] == 4 and b == sorted(b)
     assert shard.product_balanced_bounds(torch.tensor([5, 5, 5, 5], dtype=torch.int64), 1) == [0, 4]
+
+
+def test_cost_balanced_bounds():
+    prod = torch.tensor([300000, 300000, 20000, 20000, 20000, 20000, 100, 100, 100, 100] * 50, dtype=torch.int64)
+    for world in (1, 2, 4, 8):
+        b = shard.cost_balanced_bounds(prod, world, 8192, 262144)
+        assert b[0] == 0 and b[-1] == prod.numel() and all(x <= y for x, y in zip(b, b[1:]))
+        p = prod.double()
+        w = torch.where(prod <= 8192, shard.COST_NS["sorted"], torch.where(prod >= 262144, shard.COST_NS["dense"], shard.COST_NS["window"]))
+        cost = [float((p * w)[b[r]:b[r + 1]].sum()) for r in range(world)]
+        assert max(cost) - min(cost) <= 2 * float((p * w).max())          # balanced up to a row or two
+    assert shard.cost_balanced_bounds(torch.zeros(0, dtype=torch.int64), 3, 8192, 262144) == [0, 0, 0, 0]
