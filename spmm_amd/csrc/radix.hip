@@ -4,7 +4,9 @@
 // Stability inside a tile comes from walking it in memory order: each of the 4 waves owns a
 // contiguous quarter of the tile and visits it 64 keys at a time; within such a step a lane's
 // rank among the lanes holding the same digit is a ballot/popcount (the 64-wide counterpart of
-// a match-any), and per-wave digit counters in LDS carry the rank across steps.
+// a match-any), and per-wave digit counters in LDS carry the rank across steps.  The tile is
+// first put in digit order in LDS and then written out, so that consecutive lanes store to
+// consecutive addresses inside every digit's run instead of 64 scattered 4-byte stores.
 #include "common.h"
 
 namespace {
@@ -70,10 +72,16 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {   // per digit: turn the per-wave totals into per-wave bases inside the tile
+    __shared__ int32_t tbase[256];            // first position of a digit inside the tile, in digit order
+    __shared__ int32_t scan_tmp[RS_WAVES + 1];
+    __shared__ uint32_t stage_k[RS_TILE];
+    __shared__ uint32_t stage_v[HAS_VALS ? RS_TILE : 1];
+    {   // per digit: per-wave totals -> per-wave bases inside the digit, digit totals -> tile prefix
         int d = threadIdx.x, run = 0;
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ww++) { int x = wcnt[ww][d]; wcnt[ww][d] = run; run += x; }
+        int tot;
+        tbase[d] = block_exclusive_scan<RS_THREADS, int32_t>(run, scan_tmp, &tot);   // barriers inside
     }
     __syncthreads();
 #pragma unroll
@@ -81,9 +89,23 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
         int64_t i = wbase + s * 64 + lane;
         if (i < n) {
             uint32_t d = (key[s] >> shift) & 255u;
-            int64_t pos = (int64_t)gbase[d] + wcnt[w][d] + rank[s];
-            keys_out[pos] = key[s];
-            if (HAS_VALS) vals_out[pos] = vals_in[i];
+            int lp = tbase[d] + wcnt[w][d] + rank[s];
+            stage_k[lp] = key[s];
+            if (HAS_VALS) stage_v[lp] = vals_in[i];
+        }
+    }
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    const int ntile = n - tile0 < RS_TILE ? (int)(n - tile0) : RS_TILE;
+#pragma unroll
+    for (int j = 0; j < RS_STEPS; j++) {
+        const int lp = j * RS_THREADS + threadIdx.x;
+        if (lp < ntile) {
+            const uint32_t k = stage_k[lp];
+            const uint32_t d = (k >> shift) & 255u;
+            const int64_t pos = (int64_t)gbase[d] + (lp - tbase[d]);
+            keys_out[pos] = k;
+            if (HAS_VALS) vals_out[pos] = stage_v[lp];
         }
     }
 }
