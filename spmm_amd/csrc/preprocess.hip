@@ -42,36 +42,72 @@ __device__ __forceinline__ int last_le(const int32_t* __restrict__ a, int n, int
 // ---------------------------------------------------------------------------
 // Row key, bitmap.h:123-143: walk the row, sec = col / sect; when the section rises above the
 // previous element's and the running score beats the best, the PREVIOUS section becomes the
-// best and the score restarts (only then); key = best section + 1.  One wave per row: the lanes
-// read 64 elements at a time and find the places where the section rises; the state machine
-// only runs over those (at most ncol / sect per row), so a hub row of 10^5 entries costs a
-// few thousand wave instructions instead of 10^5 dependent loads.
+// best and the score restarts (only then); key = best section + 1.
+// Rows of up to RK_LONG entries: one thread per row walks it; longer rows are listed for the
+// wave kernel below.
+constexpr int RK_LONG = 128, RK_AHEAD = 8;
 __global__ void __launch_bounds__(256) k_row_keys(int32_t nrow, const int32_t* __restrict__ ip,
                                                   const int32_t* __restrict__ ix, int32_t sect,
-                                                  uint32_t* __restrict__ keys) {
+                                                  uint32_t* __restrict__ keys, int32_t* __restrict__ long_rows,
+                                                  int32_t* __restrict__ n_long) {
+    GRID_STRIDE(r, nrow) {
+        const int b = ip[r], e = ip[r + 1];
+        if (e - b > RK_LONG) {
+            long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
+            continue;
+        }
+        int best = 0, best_sec = -1, prev_sec = 0, score = 0;
+        for (int p = b; p < e; p++) {
+            const int sec = ix[p] / sect;
+            if (sec > prev_sec && score > best) { best = score; best_sec = prev_sec; score = 0; }
+            prev_sec = sec;
+            score++;
+        }
+        keys[r] = (uint32_t)(best_sec + 1);
+    }
+}
+
+// Long rows, one wave per row: the lanes read 64 elements at a time (RK_AHEAD chunks in flight)
+// and find the places where the section rises; the state machine only runs over those (at most
+// ncol / sect per row), so a hub row of 10^5 entries costs a few thousand wave instructions
+// instead of 10^5 dependent loads.
+__global__ void __launch_bounds__(256) k_row_keys_long(const int32_t* __restrict__ long_rows, const int32_t* __restrict__ n_long,
+                                                       const int32_t* __restrict__ ip, const int32_t* __restrict__ ix,
+                                                       int32_t sect, uint32_t* __restrict__ keys) {
     const int lane = threadIdx.x & 63;
-    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrow; r += nwave) {
+    const int nwave = gridDim.x * (blockDim.x >> 6), count = *n_long;
+    for (int li = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); li < count; li += nwave) {
+        const int r = long_rows[li];
         int best = 0, best_sec = -1, prev_sec = 0, score = 0;   // wave-uniform
         const int b = ip[r], e = ip[r + 1];
-        for (int p0 = b; p0 < e; p0 += 64) {
-            const int p = p0 + lane;
-            const bool valid = p < e;
-            const int sec = valid ? ix[p] / sect : 0;
-            int before = __shfl_up(sec, 1, 64);
-            if (lane == 0) before = prev_sec;
-            unsigned long long rise = __ballot(valid && sec > before);
-            const int nvalid = e - p0 < 64 ? e - p0 : 64;
-            int last = 0;                                     // elements of this chunk already counted
-            while (rise) {
-                const int at = __ffsll(rise) - 1;
-                rise &= rise - 1;
-                score += at - last;                           // elements of the previous section
-                last = at;
-                if (score > best) { best = score; best_sec = __builtin_amdgcn_readlane(before, at); score = 0; }
+        for (int q0 = b; q0 < e; q0 += 64 * RK_AHEAD) {
+            int secs[RK_AHEAD];
+#pragma unroll
+            for (int j = 0; j < RK_AHEAD; j++) {
+                const int p = q0 + j * 64 + lane;
+                secs[j] = p < e ? ix[p] / sect : 0;
             }
-            score += nvalid - last;
-            prev_sec = __builtin_amdgcn_readlane(sec, nvalid - 1);
+#pragma unroll
+            for (int j = 0; j < RK_AHEAD; j++) {
+                const int p0 = q0 + j * 64;
+                if (p0 >= e) break;                               // wave-uniform
+                const int sec = secs[j];
+                const bool valid = p0 + lane < e;
+                int before = __shfl_up(sec, 1, 64);
+                if (lane == 0) before = prev_sec;
+                unsigned long long rise = __ballot(valid && sec > before);
+                const int nvalid = e - p0 < 64 ? e - p0 : 64;
+                int last = 0;                                     // elements of this chunk already counted
+                while (rise) {
+                    const int at = __ffsll(rise) - 1;
+                    rise &= rise - 1;
+                    score += at - last;                           // elements of the previous section
+                    last = at;
+                    if (score > best) { best = score; best_sec = __builtin_amdgcn_readlane(before, at); score = 0; }
+                }
+                score += nvalid - last;
+                prev_sec = __builtin_amdgcn_readlane(sec, nvalid - 1);
+            }
         }
         if (lane == 0) keys[r] = (uint32_t)(best_sec + 1);
     }
@@ -176,9 +212,12 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
         int c = 0;
 #pragma unroll
         for (int j = 0; j < BC_ITEMS; j++) c += (q0 + j < nnz && prev[q0 + j] < s0) ? 1 : 0;
-        int tot;
-        block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
+        c = wave_reduce_sum(c);
+        if ((tid & 63) == 0) tmp[tid >> 6] = c;
+        __syncthreads();
         if (tid == 0) {
+            int tot = 0;
+            for (int i = 0; i < BC_THREADS / 64; i++) tot += tmp[i];
             st->tile_cnt[blockIdx.x] = tot;
             __threadfence();
             sh_last = atomicAdd(&st->ticket, 1) == BC_TILES - 1 ? 1 : 0;
@@ -512,7 +551,13 @@ int dev_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* 
     CHK(ws(ctx, WS_RADIX_V0, (size_t)n + 1, &v0));
     CHK(ws(ctx, WS_RADIX_K1, (size_t)n + 1, &k1));
     if (n > 0) {
-        hipLaunchKernelGGL(k_row_keys, dim3(grid_for(((int64_t)n + 3) / 4 * 256, 256, 256 * 64)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, k0);
+        int32_t *long_rows, *n_long;
+        CHK(ws(ctx, WS_MISC1, (size_t)n + 1, &long_rows));
+        CHK(ws(ctx, WS_COUNTERS, 64, &n_long));
+        HIPCHK(hipMemsetAsync(n_long, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, k0,
+                           long_rows, n_long);
+        hipLaunchKernelGGL(k_row_keys_long, dim3(1024), dim3(256), 0, ctx->stream, long_rows, n_long, A->indptr, A->indices, sect, k0);
         hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)n);
         CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, (uint32_t*)seq, n, bits_for((uint32_t)(A->ncol / sect))));
     }
