@@ -104,6 +104,36 @@ def test_product_rectangular_fp64(ctx):
     np.testing.assert_allclose(cd, Z["c_data"], rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize("log_ncol", [25, 27])
+def test_product_very_wide_b(ctx, log_ncol):
+    """B with 2^25 / 2^27 columns: the window table switches to 2^15 / 2^17-column windows (at most 1024
+    windows), so the dense kernel sweeps every table window in 2 / 8 sub-ranges, and the symbolic bitmap
+    needs 32 / 128 passes.  A's rows span every bin, up to 360 000 products."""
+    rng = np.random.default_rng(23)
+    ka, ncol = 1500, 1 << log_ncol
+    b_len = rng.integers(1, 4000, ka)
+    b_ip = np.zeros(ka + 1, np.int32)
+    b_ip[1:] = np.cumsum(b_len)
+    b_ix = np.concatenate([np.sort(rng.choice(ncol, l, replace=False)) for l in b_len]).astype(np.int32)
+    b_ix[:b_len[0]] = np.sort(rng.choice(40000, b_len[0], replace=False))         # one row crowded into a few windows
+    b_d = rng.integers(1, 4, b_ix.size).astype(np.float64)
+    rows = 260
+    a_len = np.concatenate([rng.integers(0, 4, 100), rng.integers(4, 40, 120), rng.integers(60, 180, 40)])
+    a_ip = np.zeros(rows + 1, np.int32)
+    a_ip[1:] = np.cumsum(a_len)
+    a_ix = np.concatenate([np.sort(rng.choice(ka, l, replace=False)) for l in a_len]).astype(np.int32)
+    a_d = rng.integers(1, 4, a_ix.size).astype(np.float64)
+    A, B = capi.Csr(rows, ka, a_ip, a_ix, a_d), capi.Csr(ka, ncol, b_ip, b_ix, b_d)
+    prod, _ = orc.row_products(a_ip, a_ix, b_ip)
+    assert prod.max() > 262144 and ((prod > 8192) & (prod < 262144)).any() and (prod <= 512).any()
+    c_ip, nnz_c, prods = ctx.spgemm_symbolic(A, B)
+    o_ip = orc.spgemm_symbolic(rows, ncol, a_ip, a_ix, b_ip, b_ix)
+    assert np.array_equal(c_ip, o_ip) and prods == int(prod.sum())
+    ci, cd = ctx.spgemm_numeric(A, B, c_ip)
+    oi, od, _ = orc.spgemm_numeric(ncol, (a_ip, a_ix, a_d), (b_ip, b_ix, b_d), o_ip)
+    assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+
+
 def test_product_heavy_rows_all_bins(ctx):
     """A matrix whose rows fall in every bin, including rows with more distinct output columns
     than one value sweep holds and duplicate entries in A (kept by the reference loader)."""
