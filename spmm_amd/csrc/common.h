@@ -108,6 +108,7 @@ static inline int bits_for(uint32_t max_value) {
 }
 
 #ifdef __HIPCC__
+#include <type_traits>
 // ---------------------------------------------------------------------------
 // wave / block helpers (wave = 64 lanes)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -116,14 +117,48 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
+// Wave-level scans use data-parallel-primitive moves (row shifts inside 16 lanes, then two row
+// broadcasts) for 32-bit values: a __shfl_up is a ds_bpermute, i.e. it goes through the LDS
+// pipeline that all waves of a workgroup share, and a 6-step shuffle scan by 16 waves costs about
+// 0.3 us of it (tools/ubench/barrier_cost.hip).
+__device__ __forceinline__ int dpp_shr1(int x) {   // lane i gets lane i-1's value, lane 0 keeps its own
+    return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);   // wave_shr:1
+}
+
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// running maximum over the lanes of a wave, for values >= 0
+__device__ __forceinline__ int wave_inclusive_max_nonneg(int v) {
+    int o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v) {
+    if constexpr (sizeof(T) == 4 && std::is_integral<T>::value) {
+        return (T)wave_inclusive_scan_i32((int)v);
+    } else {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T o = __shfl_up(v, d, 64);
-        if ((int)(threadIdx.x & 63) >= d) v += o;
+        for (int d = 1; d < 64; d <<= 1) {
+            T o = __shfl_up(v, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) v += o;
+        }
+        return v;
     }
-    return v;
 }
 
 template <typename T>
@@ -131,6 +166,22 @@ __device__ __forceinline__ T wave_reduce_sum(T v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
+}
+
+// Wave totals in tmp[0..NW) -> (exclusive prefix for wave w, grand total): lanes 0..NW-1 read one
+// total each and scan them inside a 16-lane row; one LDS instruction per wave instead of NW.
+template <int NW>
+__device__ __forceinline__ void combine_wave_totals_i32(const int32_t* tmp, int w, int32_t* base, int32_t* total) {
+    static_assert(NW <= 16, "the totals of a workgroup fit one 16-lane row");
+    const int lane = threadIdx.x & 63;
+    int x = lane < NW ? tmp[lane] : 0;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    if (NW > 2) x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    if (NW > 4) x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    if (NW > 8) x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    *total = __builtin_amdgcn_readlane(x, NW - 1);
+    *base = ws > 0 ? __builtin_amdgcn_readlane(x, ws - 1) : 0;
 }
 
 // Exclusive scan across a block of THREADS threads.  tmp must hold THREADS/64 + 1 elements of T
@@ -144,21 +195,26 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* tmp, T* total) {
     __syncthreads();   // protects tmp against a previous use
     if ((threadIdx.x & 63) == 63) tmp[w] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        T run = 0;
+    if constexpr (sizeof(T) == 4 && std::is_integral<T>::value) {
+        int32_t base, tot;
+        combine_wave_totals_i32<NW>((const int32_t*)tmp, w, &base, &tot);
+        *total = (T)tot;
+        return (T)base + inc - v;
+    } else {
+        T base = 0, tot = 0;
 #pragma unroll
-        for (int i = 0; i < NW; i++) { T x = tmp[i]; tmp[i] = run; run += x; }
-        tmp[NW] = run;
+        for (int i = 0; i < NW; i++) {
+            const T x = tmp[i];
+            if (i < w) base += x;
+            tot += x;
+        }
+        *total = tot;
+        return base + inc - v;
     }
-    __syncthreads();
-    T base = tmp[w];
-    *total = tmp[NW];
-    return base + inc - v;
 }
 // Variant for hot loops: one barrier.  tmp must be a buffer that no thread can still be reading
 // from an earlier call (the caller alternates buffers or has a barrier in between); it holds
-// THREADS/64 elements.  Every thread sums the wave totals itself instead of waiting for a
-// serial pass by one thread.
+// THREADS/64 elements.
 template <int THREADS, typename T>
 __device__ __forceinline__ T block_exclusive_scan_1b(T v, T* tmp, T* total) {
     constexpr int NW = THREADS / 64;
@@ -166,14 +222,21 @@ __device__ __forceinline__ T block_exclusive_scan_1b(T v, T* tmp, T* total) {
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 63) tmp[w] = inc;
     __syncthreads();
-    T base = 0, tot = 0;
+    if constexpr (sizeof(T) == 4 && std::is_integral<T>::value) {
+        int32_t base, tot;
+        combine_wave_totals_i32<NW>((const int32_t*)tmp, w, &base, &tot);
+        *total = (T)tot;
+        return (T)base + inc - v;
+    } else {
+        T base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < NW; i++) {
-        const T x = tmp[i];
-        if (i < w) base += x;
-        tot += x;
+        for (int i = 0; i < NW; i++) {
+            const T x = tmp[i];
+            if (i < w) base += x;
+            tot += x;
+        }
+        *total = tot;
+        return base + inc - v;
     }
-    *total = tot;
-    return base + inc - v;
 }
 #endif

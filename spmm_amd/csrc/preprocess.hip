@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) k_row_keys_long(const int32_t* __restrict
                 if (p0 >= e) break;                               // wave-uniform
                 const int sec = secs[j];
                 const bool valid = p0 + lane < e;
-                int before = __shfl_up(sec, 1, 64);
+                int before = dpp_shr1(sec);
                 if (lane == 0) before = prev_sec;
                 unsigned long long rise = __ballot(valid && sec > before);
                 const int nvalid = e - p0 < 64 ? e - p0 : 64;

@@ -657,13 +657,8 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                                 (int)(raw.z & 0xffffu), (int)(raw.z >> 16), (int)(raw.w & 0xffffu), (int)(raw.w >> 16)};
 #pragma unroll
                     for (int i = 1; i < U; i++) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
-                    int inc = v[U - 1];
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int o = __shfl_up(inc, d, 64);
-                        inc = (lane >= d && o > inc) ? o : inc;
-                    }
-                    int before = __shfl_up(inc, 1, 64);
+                    const int inc = wave_inclusive_max_nonneg(v[U - 1]);
+                    int before = dpp_shr1(inc);
                     const int wb = wave_ent[wv];
                     before = (lane != 0 && before > wb) ? before : wb;
 #pragma unroll
@@ -924,8 +919,12 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
 // products outside the sub-range are skipped.
 constexpr int DENSE_COLS = 16384;
 
-__device__ __forceinline__ void dense_add(double* acc, uint8_t* flags, int col, int cbase, double v) {
-    const unsigned lc = (unsigned)(col - cbase);
+// `valid` selects lanes that hold a product.  The loaded column is consumed on every path (the
+// select below), so the wait for the load is unconditional too: a load whose only use sits in a
+// branch stays "pending" for the compiler on the other path, and the next reuse of its register
+// then drains every outstanding load and store (s_waitcnt vmcnt(0)), prefetches included.
+__device__ __forceinline__ void dense_add(double* acc, uint8_t* flags, int col, int cbase, double v, bool valid = true) {
+    const unsigned lc = valid ? (unsigned)(col - cbase) : 0xffffffffu;
     if (lc < (unsigned)DENSE_COLS) {
         atomicAdd(&acc[lc], v);
         flags[lc] = 1;
@@ -942,17 +941,22 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // all entries form one index space; a batch is 256 of them, four per lane, all loaded before
 // any is used.  wmap (256 bytes, private to the wave) maps a product of the batch to the lane
 // that holds its entry: entries mark the place where they start, a running maximum fills the
-// gaps.  act(col, a*b) is called once per product; b_val is only read when WITH_VAL.
+// gaps.  act(col, a*b, valid) is called for every lane slot, valid for the products; b_val is
+// only read when WITH_VAL.
 template <bool WITH_VAL, typename F>
 __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
                                                 int rem, double a, int lane, uint8_t* wmap, F&& act) {
     uint32_t* wmap4 = (uint32_t*)wmap;
     rem = rem > 0 ? rem : 0;
     int inc = rem;
+    if (WITH_VAL) {
+        inc = wave_inclusive_scan_i32(rem);
+    } else {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        inc += lane >= d ? o : 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            inc += lane >= d ? o : 0;
+        }
     }
     const int R = __builtin_amdgcn_readlane(inc, 63);
     const int o = inc - rem;     // index of the entry's first product
@@ -969,13 +973,19 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
         v1 = v1 > v0 ? v1 : v0;
         v2 = v2 > v1 ? v2 : v1;
         v3 = v3 > v2 ? v3 : v2;
-        int run = v3;
+        // (measured: the symbolic kernel, whose LDS pipeline is nearly idle, is faster with shuffles here)
+        int run = v3, before;
+        if (WITH_VAL) {
+            run = wave_inclusive_max_nonneg(v3);
+            before = dpp_shr1(run);
+        } else {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int x = __shfl_up(run, d, 64);
-            run = (lane >= d && x > run) ? x : run;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int x = __shfl_up(run, d, 64);
+                run = (lane >= d && x > run) ? x : run;
+            }
+            before = __shfl_up(run, 1, 64);
         }
-        int before = __shfl_up(run, 1, 64);
         before = (lane != 0 && before > base) ? before : base;
         v0 = v0 > before ? v0 : before;
         v1 = v1 > before ? v1 : before;
@@ -992,12 +1002,11 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
             const int src = (int)wmap[qc - b0] - 1;
             const int pos = __shfl(so, src, 64) + qc;
             aq[j] = WITH_VAL ? __shfl(a, src, 64) : 0.0;
+            bq[j] = WITH_VAL ? b_val[pos] : 0.0;              // value first: the wait for the column covers it
             cq[j] = b_ix[pos];
-            bq[j] = WITH_VAL ? b_val[pos] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (b0 + j * 64 + lane < R) act(cq[j], aq[j] * bq[j]);
+        for (int j = 0; j < 4; j++) act(cq[j], aq[j] * bq[j], b0 + j * 64 + lane < R);
     }
 }
 
@@ -1053,9 +1062,12 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             t_nxt = Tp[1];
         }
         if (pipelined) {
+            // unconditional loads (position 0 when there is no such product): the compiler can then count
+            // them and does not drain every outstanding load at the next reuse of a register
             const int len = t_nxt - t_cur;
-            if (pi < len) { pc0 = b_ix[t_cur + pi]; pb0 = b_val[t_cur + pi]; }
-            if (pi + LA < len) { pc1 = b_ix[t_cur + pi + LA]; pb1 = b_val[t_cur + pi + LA]; }
+            const int q0 = pi < len ? t_cur + pi : 0, q1 = pi + LA < len ? t_cur + pi + LA : 0;
+            pb0 = b_val[q0]; pb1 = b_val[q1];
+            pc0 = b_ix[q0]; pc1 = b_ix[q1];
         }
     }
     __syncthreads();
@@ -1093,22 +1105,22 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 if (__ballot(len > 0) == 0ull) continue;   // nothing of this wave's entries falls into the window
                 // tier 1: products pi and pi+LA of the lane's own entry
                 if (pipelined) {
-                    if (pi < len) dense_add(acc, flags, pc0, cbase, a * pb0);
-                    if (pi + LA < len) dense_add(acc, flags, pc1, cbase, a * pb1);
+                    dense_add(acc, flags, pc0, cbase, a * pb0, pi < len);
+                    dense_add(acc, flags, pc1, cbase, a * pb1, pi + LA < len);
                 } else {
+                    // unconditional loads (position 0 when there is no such product)
                     const bool v0 = pi < len, v1 = pi + LA < len;
-                    const int q0 = v0 ? b_ix[s + pi] : -1;
-                    const double r0 = v0 ? b_val[s + pi] : 0.0;
-                    const int q1 = v1 ? b_ix[s + pi + LA] : -1;
-                    const double r1 = v1 ? b_val[s + pi + LA] : 0.0;
-                    if (v0) dense_add(acc, flags, q0, cbase, a * r0);
-                    if (v1) dense_add(acc, flags, q1, cbase, a * r1);
+                    const int p0 = v0 ? s + pi : 0, p1 = v1 ? s + pi + LA : 0;
+                    const double r0 = b_val[p0], r1 = b_val[p1];
+                    const int q0 = b_ix[p0], q1 = b_ix[p1];
+                    dense_add(acc, flags, q0, cbase, a * r0, v0);
+                    dense_add(acc, flags, q1, cbase, a * r1, v1);
                 }
                 const int rem = lane < E ? len - 2 * LA : 0;
                 unsigned long long mask_c = __ballot(rem > 256);
                 // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
                 wave_flat_sweep<true>(b_ix, b_val, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
-                                      [&](int col, double v) { dense_add(acc, flags, col, cbase, v); });
+                                      [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); });
                 // tier 3: the whole wave on one entry
                 while (mask_c) {
                     const int src = __ffsll(mask_c) - 1;
@@ -1116,26 +1128,28 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
                     const int rr = __builtin_amdgcn_readlane(rem, src);
                     const double aa = readlane_f64(a, src);
-                    for (int i = lane; i < rr; i += 256) {
+                    for (int i0 = 0; i0 < rr; i0 += 256) {   // wave-uniform trip count, unconditional loads
                         int cq[4];
                         double bq[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const bool v = i + 64 * q < rr;
-                            cq[q] = v ? b_ix[ss + i + 64 * q] : -1;
-                            bq[q] = v ? b_val[ss + i + 64 * q] : 0.0;
+                            const int i = i0 + 64 * q + lane;
+                            const int ic = i < rr ? i : rr - 1;          // lanes past the end repeat the last product
+                            bq[q] = b_val[ss + ic];
+                            cq[q] = b_ix[ss + ic];
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (i + 64 * q < rr) dense_add(acc, flags, cq[q], cbase, aa * bq[q]);
+                        for (int q = 0; q < 4; q++) dense_add(acc, flags, cq[q], cbase, aa * bq[q], i0 + 64 * q + lane < rr);
                     }
                 }
             }
-            if (pipelined && w + 1 < nbase) {
-                // tier-1 loads of the next window stay in flight across the output pass
-                const int len = t_nxt - t_cur;
-                if (pi < len) { pc0 = b_ix[t_cur + pi]; pb0 = b_val[t_cur + pi]; }
-                if (pi + LA < len) { pc1 = b_ix[t_cur + pi + LA]; pb1 = b_val[t_cur + pi + LA]; }
+            if (pipelined) {
+                // tier-1 loads of the next window stay in flight across the output pass (unconditional,
+                // see above; after the last window they read position 0)
+                const int len = w + 1 < nbase ? t_nxt - t_cur : 0;
+                const int q0 = pi < len ? t_cur + pi : 0, q1 = pi + LA < len ? t_cur + pi + LA : 0;
+                pb0 = b_val[q0]; pb1 = b_val[q1];
+                pc0 = b_ix[q0]; pc1 = b_ix[q1];
             }
             DENSE_STAMP(0)
             __syncthreads();
@@ -1260,7 +1274,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
             unsigned long long mask_c = __ballot(rem > 256);
             // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
             wave_flat_sweep<false>(b_ix, nullptr, s + 2 * LA, rem <= 256 ? rem : 0, 0.0, lane, wmap,
-                                   [&](int col, double) { sym_mark(bits, col, cbase); });
+                                   [&](int col, double, bool valid) { if (valid) sym_mark(bits, col, cbase); });
             // tier 3: the whole wave on one entry
             while (mask_c) {
                 const int src = __ffsll(mask_c) - 1;
