@@ -546,10 +546,14 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     // end of the window that starts at table window w0 (block-uniform)
     auto window_end = [&](int w0) {
         if (!(NUMERIC && adaptive)) return w0 + m < nbase ? w0 + m : nbase;
+        // one LDS read per wave: lane l looks at the window of 1 + l granules; the sums rise with l, so
+        // the window takes the leading run of lanes whose sum still fits
         const int j0 = w0 / gsz;
         const uint32_t base = cs[j0];
-        int j1 = j0 + 1;
-        while (j1 < nh && j1 - j0 < gmax && cs[j1 + 1] - base <= (uint32_t)(U * THREADS)) j1++;
+        const int jl = j0 + lane + 1 < nh ? j0 + lane + 1 : nh;
+        const bool fits = lane >= 1 && lane < gmax && j0 + lane < nh && cs[jl] - base <= (uint32_t)(U * THREADS);
+        const unsigned long long m = __ballot(fits) >> 1;          // bit i: the window may grow to 2 + i granules
+        const int j1 = j0 + 1 + (__ffsll(~m) - 1);
         return j1 * gsz < nbase ? j1 * gsz : nbase;
     };
     int w1_cur = window_end(0), w1_next = 0;
@@ -743,20 +747,44 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
             continue;
         }
         // ---- rank prefix over the bitmap words ---------------------------------
+        // A window of full width (the common case for light rows) moves a thread's words with 16-byte
+        // LDS accesses: the LDS pipeline is shared by all 16 waves, and most of a sparse window's LDS
+        // instructions are these per-word reads, writes and clears.
+        const bool fullw = NUMERIC && WPT % 4 == 0 && wpt == WPT;
         int s = 0;
         uint32_t myw[WPT];
+        if (fullw) {
 #pragma unroll
-        for (int j = 0; j < WPT; j++) {
-            myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
-            s += __popc(myw[j]);
+            for (int j = 0; j < WPT / 4; j++) {
+                const uint4 x = ((const uint4*)bits)[tid * (WPT / 4) + j];
+                myw[4 * j] = x.x; myw[4 * j + 1] = x.y; myw[4 * j + 2] = x.z; myw[4 * j + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WPT; j++) myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
         }
+#pragma unroll
+        for (int j = 0; j < WPT; j++) s += __popc(myw[j]);
         int cntw;
         const int ex = block_exclusive_scan_1b<THREADS, int32_t>(s, tmp_pre, &cntw);
         if (!(dbg & 32)) {
-            int r = ex;
+            if (fullw) {
+                uint32_t r = (uint32_t)ex;
 #pragma unroll
-            for (int j = 0; j < WPT; j++)
-                if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
+                for (int j = 0; j < WPT / 4; j++) {
+                    uint4 x;
+                    x.x = r; r += __popc(myw[4 * j]);
+                    x.y = r; r += __popc(myw[4 * j + 1]);
+                    x.z = r; r += __popc(myw[4 * j + 2]);
+                    x.w = r; r += __popc(myw[4 * j + 3]);
+                    ((uint4*)pre)[tid * (WPT / 4) + j] = x;
+                }
+            } else {
+                int r = ex;
+#pragma unroll
+                for (int j = 0; j < WPT; j++)
+                    if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
+            }
         }
         const bool staged = cntw <= VALS;
         WIN_STAMP(3)   // rank prefix
@@ -889,9 +917,16 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                 }
             }
         }
+        if (fullw) {
 #pragma unroll
-        for (int j = 0; j < WPT; j++)
-            if (j < wpt) bits[tid * wpt + j] = 0u;
+            for (int j = 0; j < WPT / 4; j++)
+                if (myw[4 * j] | myw[4 * j + 1] | myw[4 * j + 2] | myw[4 * j + 3])
+                    ((uint4*)bits)[tid * (WPT / 4) + j] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < WPT; j++)
+                if (j < wpt) bits[tid * wpt + j] = 0u;
+        }
         out += cntw;
         if (NUMERIC && single_chunk && !fast) __syncthreads();   // staged column ids are read before the map is cleared
         WIN_STAMP(6)   // output
