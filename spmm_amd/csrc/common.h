@@ -42,7 +42,7 @@ void spmm_set_error(const char* fmt, ...);
 // calls of the same size allocate nothing.
 enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
-    WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_ESC_M, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
+    WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_ESC_M, WS_LIST_GIANT, WS_GSLOT, WS_WCNT, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
     WS_WINPTR, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_P0, WS_P1, WS_P2, WS_P3, WS_P4, WS_P5, WS_P6, WS_P7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     WS_NSLOTS
@@ -55,6 +55,8 @@ struct plan_cache {
     bool valid = false;
     const void *a_ip = nullptr, *a_ix = nullptr, *b_ip = nullptr, *b_ix = nullptr;
     int a_nrow = 0, b_nrow = 0, b_ncol = 0, b_nnz = 0;
+    int n_giant = 0;          // dense rows with more than giant_len entries, numbered by the symbolic call
+    bool has_wcnt = false;    // the symbolic kernel wrote their per-window counts
 };
 
 struct spmm_ctx {
@@ -63,6 +65,9 @@ struct spmm_ctx {
     bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int adaptive = 1;       // numeric k_win: window widths follow the row's product distribution
     int sym_cfg = 0;        // symbolic window kernel: 0 = k_symd (tiered sweep), 1 = k_win
+    int giant_tasks = 16, giant_chunk = 1;   // workgroups per split row; consecutive table windows per turn
+    int giant_len = 8192;   // dense rows with more entries of A than this are the ones that get split
+    int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = 1 << 18;   // rows with at least this many intermediate products use k_dense; 0 = off
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     std::vector<phase_rec> recs;       // recorded this profiling session

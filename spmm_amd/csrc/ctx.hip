@@ -41,6 +41,10 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     c->own_stream = true;
     if (const char* e = getenv("SPMM_DENSE_MIN")) c->dense_min = atoll(e);
     if (const char* e = getenv("SPMM_SYM_CFG")) c->sym_cfg = atoi(e);
+    if (const char* e = getenv("SPMM_GIANT_TASKS")) c->giant_tasks = atoi(e) > 1 ? atoi(e) : 2;
+    if (const char* e = getenv("SPMM_GIANT_CHUNK")) c->giant_chunk = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("SPMM_SPLIT_GIANT")) c->split_giant = atoi(e);
+    if (const char* e = getenv("SPMM_GIANT_LEN")) c->giant_len = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("SPMM_ADAPTIVE")) c->adaptive = atoi(e);
     if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);
     if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e) != 0;

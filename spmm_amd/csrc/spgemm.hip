@@ -40,7 +40,7 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_N = 8 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_N = 12 };
 
 // ---------------------------------------------------------------------------
 // P_i per row, one wave per row.
@@ -87,14 +87,24 @@ __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_e
                                                   int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
                                                   int32_t* __restrict__ list_m,
                                                   int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
-                                                  long long dense_thr, long long* __restrict__ counters) {
+                                                  long long dense_thr, int giant_mode, int giant_len, int32_t* __restrict__ gslot,
+                                                  int32_t* __restrict__ list_g, long long* __restrict__ counters) {
     int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
     if (row < row_end) {
         p = prod[row];
+        const int len_a = a_ip[row + 1] - a_ip[row];
         // the radix expand-sort-compress kernels index the entries of a row with 16 bits
-        const bool many_entries = a_ip[row + 1] - a_ip[row] > 65535;
-        if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) {
+        const bool many_entries = len_a > 65535;
+        // Dense rows with very many entries are a long serial chain for one workgroup.  The symbolic call
+        // (giant_mode 1) numbers them; a numeric call that can use the symbolic call's per-window counts
+        // (giant_mode 2) takes them out of the window list and splits each over several workgroups.
+        const bool is_win = p > ESC_R_CAP || (p > ESC_S_CAP && many_entries);   // the row takes the window kernels
+        if (giant_mode == 1 && is_win && p >= dense_thr && len_a > giant_len)
+            gslot[row] = (int)atomicAdd((unsigned long long*)&counters[CNT_GIANT_ALL], 1ull);
+        if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) {
+            list_g[(int)atomicAdd((unsigned long long*)&counters[CNT_GIANT], 1ull)] = (int32_t)row;
+        } else if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) {
             list_m[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_M], 1ull)] = (int32_t)row;
         } else if (p > ESC_L_CAP || (p > ESC_S_CAP && many_entries)) {
             int at = (int)atomicAdd((unsigned long long*)&counters[CNT_WIN], 1ull);
@@ -1052,7 +1062,11 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    const int32_t* __restrict__ winptr, int nbase, int shift,
                                                    const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                    int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg,
-                                                   unsigned long long* __restrict__ stamps) {
+                                                   unsigned long long* __restrict__ stamps, int ntask, int chunk,
+                                                   const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt) {
+    // ntask > 1: the row is shared by ntask workgroups; workgroup t of a row takes the table windows
+    // t, t + ntask, ... and finds the place of a window's entries in the row of C from the per-window
+    // counts of the symbolic phase (at most THREADS table windows).
     constexpr int NW = THREADS / 64;
     static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1060,9 +1074,11 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     uint8_t* flags = (uint8_t*)(acc + DENSE_COLS);
     int32_t* tmp = (int32_t*)(flags + DENSE_COLS);   // two scan buffers of NW, used alternately
     uint8_t* wmap = (uint8_t*)(tmp + 2 * NW) + (threadIdx.x >> 6) * 256;   // 256 bytes per wave
+    int32_t* pre = (int32_t*)((uint8_t*)(tmp + 2 * NW) + NW * 256);          // THREADS window offsets (shared rows)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row = list[blockIdx.x];
+    const int task = ntask > 1 ? (int)(blockIdx.x % (unsigned)ntask) : 0;
+    const int row = list[ntask > 1 ? blockIdx.x / (unsigned)ntask : blockIdx.x];
     const int a0 = a_ip[row];
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
@@ -1071,11 +1087,18 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     const int lgE = dbg ? dbg : lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
     const int E = 1 << lgE, LA = 64 >> lgE;
     const int npass = (lenA + E * NW - 1) / (E * NW);
-    const bool cached = npass == 1;
+    const bool cached = npass == 1 && ntask == 1;
     const int el = lane & (E - 1), pi = lane >> lgE;
     const int nsub = shift > 14 ? 1 << (shift - 14) : 1;
     const bool pipelined = cached && nsub == 1;
     int64_t out = c_ip[row] - c_ip[row_beg];
+    const int64_t out_row = out;
+    if (ntask > 1) {
+        const int v = tid < nbase ? (int)wcnt[(int64_t)gslot[row] * nbase + tid] : 0;
+        int tot;
+        const int ex = block_exclusive_scan<THREADS, int32_t>(v, tmp, &tot);
+        pre[tid] = ex;   // visible after the barrier that follows the clearing of the accumulators
+    }
 
     for (int i = tid; i < DENSE_COLS; i += THREADS) acc[i] = 0.0;
     for (int i = tid; i < DENSE_COLS / 4; i += THREADS) ((uint32_t*)flags)[i] = 0u;
@@ -1113,7 +1136,11 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     if (STAMP && tid == 0) st_w = st_t = win_clock();
 #define DENSE_STAMP(i) if (STAMP && tid == 0) { const unsigned long long n_ = win_clock(); st[i] += n_ - st_t; st_t = n_; }
     int flip = 0;
-    for (int w = 0; w < nbase; w++) {
+    for (int wi = 0;; wi++) {
+        // workgroup t of a shared row takes chunks t, t + ntask, ... of `chunk` consecutive table windows
+        const int w = ntask > 1 ? ((wi / chunk) * ntask + task) * chunk + wi % chunk : wi;
+        if (w >= nbase) break;
+        if (ntask > 1) out = out_row + pre[w];
         int s_c = 0, len_c = 0;
         if (cached) {
             s_c = t_cur;
@@ -1251,6 +1278,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
 // SYM_COLS columns per pass (a whole row of C for matrices up to that width), a product costs one
 // 4-byte load and one ds_or_b32, and the row count is the popcount of the bitmap.
 constexpr int SYM_COLS = 1 << 20;
+static_assert(SYM_COLS / 1024 <= (1 << WIN_SHIFT_MIN), "a thread's share of the bitmap stays inside one table window");
 
 __device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
     const unsigned lc = (unsigned)(col - cbase);
@@ -1261,7 +1289,8 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                   const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
                                                   const int32_t* __restrict__ winptr, int nbase, int shift,
-                                                  int32_t* __restrict__ rowcnt) {
+                                                  int32_t* __restrict__ rowcnt, const int32_t* __restrict__ gslot,
+                                                  uint32_t* __restrict__ wcnt) {
     constexpr int NW = THREADS / 64;
     constexpr int WORDS = SYM_COLS / 32;
     constexpr int WPT = WORDS / THREADS;
@@ -1281,6 +1310,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
     const int npass = (lenA + E * NW - 1) / (E * NW);
     const int el = lane & (E - 1), pi = lane >> lgE;
     const int mwin = SYM_COLS >> shift;   // table windows per bitmap pass
+    const int slot = gslot[row];          // >= 0: the numeric phase wants this row's entries per table window
 
     for (int i = tid; i < WORDS / 4; i += THREADS) ((uint4*)bits)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) tmp[0] = 0;
@@ -1336,6 +1366,8 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
             if (cj) ((uint4*)bits)[tid * (WPT / 4) + j] = make_uint4(0u, 0u, 0u, 0u);
             cnt += cj;
         }
+        // the thread's 32*WPT columns lie inside one table window (windows have at least 2^14 columns)
+        if (slot >= 0 && cnt) atomicAdd(&wcnt[(int64_t)slot * nbase + w0 + ((tid * (32 * WPT)) >> shift)], (uint32_t)cnt);
         cnt = wave_reduce_sum(cnt);
         if (lane == 0 && cnt) atomicAdd(&tmp[0], cnt);
         __syncthreads();
@@ -1345,7 +1377,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 
 constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16 + 16 * 256; }
 
-constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * (8 + 256); }
+constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * (8 + 256) + (size_t)threads * 4; }
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
@@ -1387,8 +1419,10 @@ int check_csr_args(const spmm_csr* M) {
 // with the same device arrays as the last symbolic call (the normal sequence).
 struct Bins {
     int64_t* prod;
-    int32_t *list_s, *list_l, *list_m, *list_w;
-    long long n_s, n_l, n_m, n_w, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
+    int32_t *list_s, *list_l, *list_m, *list_w, *list_g;   // list_g: dense rows split into window ranges
+    int32_t* gslot;      // row -> slot of its per-window counts, or -1
+    uint32_t* wcnt;      // [slot][table window] entries of C, written by the symbolic kernel
+    long long n_s, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
 };
@@ -1430,6 +1464,8 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_MISC1, (size_t)nrow + 1, &key_w0));
     CHK(ws(ctx, WS_MISC2, (size_t)nrow + 1, &key_w1));
     CHK(ws(ctx, WS_LIST_WIN, (size_t)nrow + 1, &out->list_w));
+    CHK(ws(ctx, WS_LIST_GIANT, (size_t)nrow + 1, &out->list_g));
+    CHK(ws(ctx, WS_GSLOT, (size_t)nrow + 1, &out->gslot));
     out->shift = table_shift(B->ncol, ctx->dense_min);
     out->nbase = (int)(((int64_t)B->ncol + (1ll << out->shift) - 1) >> out->shift);
     if (out->nbase < 1) out->nbase = 1;
@@ -1454,9 +1490,22 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     int32_t nr = row_end - row_beg;
     const long long dense_thr = dense_threshold(ctx);
+    // the symbolic call numbers the giant rows; a numeric call on the same matrices splits them when the
+    // symbolic kernel left their per-window counts
+    const bool can_count = ctx->split_giant && ctx->sym_cfg == 0 && out->shift <= 20 && out->nbase >= 2 * ctx->giant_tasks * ctx->giant_chunk &&
+                           out->nbase <= 1024;
+    const int giant_mode = fresh ? (can_count ? 1 : 0) : (hit && pc.has_wcnt ? 2 : 0);
+    if (!hit) {
+        pc.has_wcnt = false;
+        pc.n_giant = 0;
+    }
+    if (fresh) {
+        HIPCHK(hipMemsetAsync(out->gslot, 0xff, sizeof(int32_t) * ((size_t)nrow + 1), ctx->stream));
+    }
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, row_beg, row_end,
-                           out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, counters);
+                           out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, giant_mode,
+                           ctx->giant_len, out->gslot, out->list_g, counters);
     long long* h = (long long*)ctx->pinned;
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1473,7 +1522,16 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->n_m = h[CNT_ESC_M];
     out->n_w = h[CNT_WIN];
     out->n_dense = h[CNT_DENSE];
+    out->n_g = h[CNT_GIANT];
     out->products = h[CNT_PRODUCTS];
+    if (giant_mode == 1) pc.n_giant = (int)h[CNT_GIANT_ALL];
+    out->wcnt = nullptr;
+    if (pc.n_giant > 0 && giant_mode != 0) {
+        CHK(ws(ctx, WS_WCNT, (size_t)pc.n_giant * out->nbase + 1, &out->wcnt));
+        if (giant_mode == 1) {
+            HIPCHK(hipMemsetAsync(out->wcnt, 0, sizeof(uint32_t) * ((size_t)pc.n_giant * out->nbase + 1), ctx->stream));
+        }
+    }
     if (out->n_w > 0)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
     if (!hit && B->nrow > 0) {
@@ -1515,7 +1573,7 @@ template <bool NUMERIC>
 int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins_in, int32_t* rowcnt,
                 const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
     Bins bins = bins_in;
-    if (NUMERIC && bins.n_dense > 0) {
+    if (NUMERIC && (bins.n_dense > 0 || bins.n_g > 0)) {
         int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
         static_assert(dl <= 160 * 1024, "LDS budget of one CU");
@@ -1523,9 +1581,15 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         unsigned long long* stamps;
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
-        hipLaunchKernelGGL(kd, dim3((unsigned)bins.n_dense), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr, A->indices,
-                           A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix, c_val, ctx->win_dbg >> 8,
-                           stamps);
+        // rows with very many entries first, each shared by giant_tasks workgroups
+        if (bins.n_g > 0)
+            hipLaunchKernelGGL(kd, dim3((unsigned)(bins.n_g * ctx->giant_tasks)), dim3(1024), dl, ctx->stream, bins.list_g, A->indptr,
+                               A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
+                               c_val, ctx->win_dbg >> 8, stamps, ctx->giant_tasks, ctx->giant_chunk, bins.gslot, bins.wcnt);
+        if (bins.n_dense > 0)
+            hipLaunchKernelGGL(kd, dim3((unsigned)bins.n_dense), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr, A->indices,
+                               A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix, c_val,
+                               ctx->win_dbg >> 8, stamps, 1, 1, bins.gslot, bins.wcnt);
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;
         bins.n_w -= bins.n_dense;
@@ -1537,7 +1601,8 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         auto ks = k_symd<1024>;
         HIPCHK(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
         hipLaunchKernelGGL(ks, dim3((unsigned)bins.n_w), dim3(1024), sl, ctx->stream, bins.list_w, A->indptr, A->indices,
-                           B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt);
+                           B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt, bins.gslot, bins.wcnt);
+        ctx->plan.has_wcnt = bins.wcnt != nullptr;   // the numeric call may now split the numbered rows
         phase_end(ctx, phs);
         bins.n_w = 0;
     }
@@ -1661,7 +1726,7 @@ extern "C" int spmm_spgemm_numeric_dev(spmm_ctx* ctx, const spmm_csr* A, const s
     if (row_beg == row_end) return SPMM_OK;
     Bins bins;
     CHK(build_bins(ctx, A, B, row_beg, row_end, false, &bins));
-    ARGCHK(bins.n_s + bins.n_l + bins.n_m + bins.n_w == 0 || (c_indices != nullptr && c_data != nullptr));
+    ARGCHK(bins.n_s + bins.n_l + bins.n_m + bins.n_w + bins.n_g == 0 || (c_indices != nullptr && c_data != nullptr));
     CHK(launch_rows<true>(ctx, A, B, bins, nullptr, c_indptr, row_beg, c_indices, c_data));
     return SPMM_OK;
 }

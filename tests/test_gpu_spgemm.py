@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 # Kernel selections the library reads from the environment when a context is created: the default
 # plan, every window row through the dense-accumulator kernel, the dense kernel off (cursor kernel
 # with 2^15-column table windows), and the cursor kernel for the symbolic phase with fixed-width
-# numeric windows.
+# numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel.
 PLANS = {
     "default": {},
     "dense_all": {"SPMM_DENSE_MIN": "1"},
     "dense_off": {"SPMM_DENSE_MIN": "0"},
     "cursor_sym_fixed_windows": {"SPMM_SYM_CFG": "1", "SPMM_ADAPTIVE": "0"},
+    "split_rows": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8"},
 }
 
 
@@ -165,6 +166,45 @@ def test_product_heavy_rows_all_bins(ctx):
     oi, od, _ = orc.spgemm_numeric(n, (ip, ix, d), (ip, ix, d), o_ip)
     assert np.array_equal(ci, oi)
     assert np.array_equal(cd, od)              # small integers: exact
+
+
+def test_product_rows_shared_by_workgroups(ctx):
+    """Rows of A with more than 8192 entries and at least 2^18 products: the numeric phase splits such a row
+    over several workgroups by table windows, placed by the symbolic phase's per-window counts.  Checked for the
+    whole matrix, for row ranges, and for a numeric call whose symbolic counts were replaced by another
+    product's in between (the rows then go through the unsplit kernel)."""
+    rng = np.random.default_rng(41)
+    ka, ncol, rows = 30000, 1 << 20, 40
+    b_len = rng.integers(20, 120, ka)
+    b_len[:50] = rng.integers(3000, 9000, 50)                  # long rows of B: whole-wave sweeps
+    b_ip = np.zeros(ka + 1, np.int32)
+    b_ip[1:] = np.cumsum(b_len)
+    skew = (rng.random(int(b_len.sum())) ** 3 * ncol).astype(np.int64)   # crowded towards low columns
+    b_rows = [np.unique(skew[b_ip[i]:b_ip[i + 1]]) for i in range(ka)]
+    b_ix = np.concatenate(b_rows).astype(np.int32)
+    b_ip[1:] = np.cumsum([r.size for r in b_rows])
+    b_d = rng.integers(1, 4, b_ix.size).astype(np.float64)
+    a_len = np.concatenate([[20000, 9000, 8193, 8192, 5000], rng.integers(0, 3000, rows - 5)])
+    a_ip = np.zeros(rows + 1, np.int32)
+    a_ip[1:] = np.cumsum(a_len)
+    a_ix = np.concatenate([np.sort(rng.choice(ka, l, replace=False)) for l in a_len]).astype(np.int32)
+    a_d = rng.integers(1, 4, a_ix.size).astype(np.float64)
+    A, B = capi.Csr(rows, ka, a_ip, a_ix, a_d), capi.Csr(ka, ncol, b_ip, b_ix, b_d)
+    prod, _ = orc.row_products(a_ip, a_ix, b_ip)
+    assert prod[:4].min() >= 1 << 18
+    o_ip = orc.spgemm_symbolic(rows, ncol, a_ip, a_ix, b_ip, b_ix)
+    oi, od, _ = orc.spgemm_numeric(ncol, (a_ip, a_ix, a_d), (b_ip, b_ix, b_d), o_ip)
+    c_ip, nnz_c, prods = ctx.spgemm_symbolic(A, B)
+    assert np.array_equal(c_ip, o_ip) and prods == int(prod.sum())
+    ci, cd = ctx.spgemm_numeric(A, B, c_ip)
+    assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+    for r0, r1 in [(0, 1), (1, 7), (3, rows)]:
+        ci2, cd2 = ctx.spgemm_numeric(A, B, c_ip, r0, r1)
+        assert np.array_equal(ci2, oi[o_ip[r0]:o_ip[r1]]) and np.array_equal(cd2, od[o_ip[r0]:o_ip[r1]])
+    Z = golden_npz("spgemm_rmat10")
+    ctx.spgemm(_ones_csr(1024, Z["row"], Z["col"]))          # another product's plan in between
+    ci, cd = ctx.spgemm_numeric(A, B, c_ip)
+    assert np.array_equal(ci, oi) and np.array_equal(cd, od)
 
 
 def test_product_rejects_unsorted_b(ctx):
