@@ -1062,11 +1062,15 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    const int32_t* __restrict__ winptr, int nbase, int shift,
                                                    const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                    int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg,
-                                                   unsigned long long* __restrict__ stamps, int ntask, int chunk,
+                                                   unsigned long long* __restrict__ stamps, const int32_t* __restrict__ list_g,
+                                                   int n_shared, int ntask_shared, int chunk,
                                                    const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt) {
-    // ntask > 1: the row is shared by ntask workgroups; workgroup t of a row takes the table windows
-    // t, t + ntask, ... and finds the place of a window's entries in the row of C from the per-window
-    // counts of the symbolic phase (at most THREADS table windows).
+    // The first n_shared workgroups work on the rows of list_g, ntask_shared workgroups per row: workgroup
+    // t of a row takes the table windows t, t + ntask, ... (in chunks of `chunk`) and finds the place of a
+    // window's entries in the row of C from the per-window counts of the symbolic phase (at most THREADS
+    // table windows).  The other workgroups take one row of `list` each.
+    const bool shared = blockIdx.x < (unsigned)n_shared;
+    const int ntask = shared ? ntask_shared : 1;
     constexpr int NW = THREADS / 64;
     static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1077,8 +1081,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     int32_t* pre = (int32_t*)((uint8_t*)(tmp + 2 * NW) + NW * 256);          // THREADS window offsets (shared rows)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int task = ntask > 1 ? (int)(blockIdx.x % (unsigned)ntask) : 0;
-    const int row = list[ntask > 1 ? blockIdx.x / (unsigned)ntask : blockIdx.x];
+    const int task = shared ? (int)(blockIdx.x % (unsigned)ntask) : 0;
+    const int row = shared ? list_g[blockIdx.x / (unsigned)ntask] : list[blockIdx.x - (unsigned)n_shared];
     const int a0 = a_ip[row];
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
@@ -1582,14 +1586,11 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
         // rows with very many entries first, each shared by giant_tasks workgroups
-        if (bins.n_g > 0)
-            hipLaunchKernelGGL(kd, dim3((unsigned)(bins.n_g * ctx->giant_tasks)), dim3(1024), dl, ctx->stream, bins.list_g, A->indptr,
-                               A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
-                               c_val, ctx->win_dbg >> 8, stamps, ctx->giant_tasks, ctx->giant_chunk, bins.gslot, bins.wcnt);
-        if (bins.n_dense > 0)
-            hipLaunchKernelGGL(kd, dim3((unsigned)bins.n_dense), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr, A->indices,
-                               A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix, c_val,
-                               ctx->win_dbg >> 8, stamps, 1, 1, bins.gslot, bins.wcnt);
+        const int n_shared = (int)bins.n_g * ctx->giant_tasks;
+        hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + bins.n_dense)), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr,
+                           A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
+                           c_val, ctx->win_dbg >> 8, stamps, bins.list_g, n_shared, ctx->giant_tasks, ctx->giant_chunk,
+                           bins.gslot, bins.wcnt);
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;
         bins.n_w -= bins.n_dense;
