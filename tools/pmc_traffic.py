@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the two numeric window kernels from the FETCH_SIZE / WRITE_SIZE passes of
+tools/prof_pmc.sh.  FETCH_SIZE and WRITE_SIZE count kilobytes; on gfx950 FETCH_SIZE counts a 128-byte
+request as 64 bytes, so reads are doubled (k_digest streams 12 bytes per entry of C exactly once and
+serves as the calibration).
+usage: pmc_traffic.py <pmc output dir> "<workload string of bench.py>" "<command>" > profiles/..json"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, workload, command = sys.argv[1:4]
+tot = defaultdict(lambda: defaultdict(float))
+calls = defaultdict(lambda: defaultdict(int))
+for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        short = ("k_dense" if "k_dense<" in name else "k_win<numeric>" if "k_win<1024, 8192, 8192" in name else
+                 "k_digest" if "k_digest" in name else None)
+        if short:
+            tot[short][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[short][r["Counter_Name"]] += 1
+kernels = {}
+for k in ("k_dense", "k_win<numeric>", "k_digest"):
+    if k not in tot:
+        continue
+    n = calls[k]["FETCH_SIZE"]
+    rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / n
+    wr = tot[k]["WRITE_SIZE"] * 1024 / calls[k]["WRITE_SIZE"]
+    kernels[k] = dict(fetch_kb_total=int(tot[k]["FETCH_SIZE"]), write_kb_total=int(tot[k]["WRITE_SIZE"]), launches=n,
+                      read_bytes_per_launch=int(rd), write_bytes_per_launch=int(wr), hbm_bytes_per_launch=int(rd + wr))
+print(json.dumps(dict(workload=workload, command=command,
+                      note="rocprofv3 --pmc, separate passes; FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 "
+                           "bytes); calibration: k_digest streams 12 B per entry of C once",
+                      kernels=kernels), indent=1))
