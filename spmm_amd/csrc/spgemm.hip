@@ -1055,6 +1055,9 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
     }
 }
 
+#ifndef DENSE_TQ
+#define DENSE_TQ 4
+#endif
 template <int THREADS, bool STAMP>
 __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                    const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
@@ -1110,6 +1113,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     const int32_t* Tp = winptr;
     double av = 0.0;
     int t_cur = 0, t_nxt = 0;
+    int tq[DENSE_TQ];
+#pragma unroll
+    for (int j = 0; j < DENSE_TQ; j++) tq[j] = 0;
     bool have = false;
     // tier-1 products of the coming window, loaded one window ahead (pipelined rows)
     int pc0 = 0, pc1 = 0;
@@ -1150,7 +1156,17 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             s_c = t_cur;
             len_c = t_nxt - t_cur;
             t_cur = t_nxt;
-            if (have && w + 2 <= nbase) t_nxt = Tp[w + 2];   // bound of the next window, used one iteration later
+            // bounds of the coming windows, DENSE_TQ per load turn, so that the table line of an entry is
+            // requested once per DENSE_TQ windows (the line does not survive in the L2 from window to window)
+            const int tph = w & (DENSE_TQ - 1);
+            if (tph == 0 && have) {
+#pragma unroll
+                for (int j = 0; j < DENSE_TQ; j++)
+                    if (w + 2 + j <= nbase) tq[j] = Tp[w + 2 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < DENSE_TQ; j++)
+                if (tph == j) t_nxt = tq[j];
         }
         for (int sub = 0; sub < nsub; sub++) {
             const int cbase = (w << shift) + sub * DENSE_COLS;
@@ -1790,7 +1806,7 @@ extern "C" int spmm_spgemm_symbolic(spmm_ctx* ctx, const spmm_csr* A, const spmm
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (nnz_c) *nnz_c = nz;
     float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->last_ms = ms;
     return SPMM_OK;
 }
@@ -1824,7 +1840,7 @@ extern "C" int spmm_spgemm_numeric(spmm_ctx* ctx, const spmm_csr* A, const spmm_
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->last_ms = ms;
     return SPMM_OK;
 }
