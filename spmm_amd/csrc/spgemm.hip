@@ -1055,6 +1055,19 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
     }
 }
 
+// 16-byte stores to addresses that are only element aligned (the compiler splits such a store; the hardware
+// takes it).  The no-op keeps the next instruction from overwriting the data registers too early.
+typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_b128(int32_t* p, int a, int b, int c, int d) {
+    const v4i32 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_b128(double* p, double a, double b) {
+    const v2f64 v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+
 #ifndef DENSE_TQ
 #define DENSE_TQ 4
 #endif
@@ -1265,16 +1278,34 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             int r = block_exclusive_scan_1b<THREADS, int32_t>(__popc(m16), tmp + flip, &total);
             DENSE_STAMP(3)
             if (wave_has) {
+                // A thread's entries are consecutive in C: column ids go out four per store and values two per
+                // store (8-byte aligned 16-byte stores), single stores for what is left.
+                const int cnt = __popc(m16);
+                int32_t* const pi = c_ix + out + r;
+                double* const pv = c_val + out + r;
                 unsigned mm = m16;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    if (__ballot(mm != 0u) == 0ull) break;
-                    if (mm) {
-                        const int lc = tid * 16 + __ffs(mm) - 1;
+                for (int g = 0; g < 4; g++) {
+                    if (__ballot(cnt > 4 * g) == 0ull) break;   // wave-uniform
+                    int id[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        id[j] = cbase + tid * 16 + __ffs(mm) - 1;   // garbage once mm is empty, not stored then
                         mm &= mm - 1u;
-                        c_ix[out + r + i] = cbase + lc;
-                        c_val[out + r + i] = vr[i];
                     }
+                    if (cnt >= 4 * g + 4) {
+                        store_b128(pi + 4 * g, id[0], id[1], id[2], id[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (cnt > 4 * g + j) pi[4 * g + j] = id[j];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    if (__ballot(cnt > 2 * g) == 0ull) break;
+                    if (cnt >= 2 * g + 2) store_b128(pv + 2 * g, vr[2 * g], vr[2 * g + 1]);
+                    else if (cnt == 2 * g + 1) pv[2 * g] = vr[2 * g];
                 }
             }
             out += total;
