@@ -383,7 +383,7 @@ constexpr size_t escr_lds_bytes() {
 // ---------------------------------------------------------------------------
 // Window-pointer table of B: T[k][w] = first position of row k whose column id is >= w << shift,
 // for w = 0..nbase (T[k][nbase] = end of row k).  With it the part of B row k that falls into a
-// column window is known without touching B's column ids.  One wave per row.
+// column window is known without touching B's column ids.  One wave per row, one lane per window.
 __global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __restrict__ b_ip,
                                                 const int32_t* __restrict__ b_ix, int shift, int nbase,
                                                 int32_t* __restrict__ winptr) {
@@ -392,16 +392,18 @@ __global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __
     for (int64_t k = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nrowB; k += nw) {
         const int r0 = b_ip[k], r1 = b_ip[k + 1];
         int32_t* T = winptr + k * (int64_t)(nbase + 1);
-        if (r0 == r1) {
-            for (int w = lane; w <= nbase; w += 64) T[w] = r0;
-            continue;
-        }
-        for (int p = r0 + lane; p < r1; p += 64) {
-            int wcur = b_ix[p] >> shift;
-            int wprev = p == r0 ? -1 : (b_ix[p - 1] >> shift);
-            for (int w = wprev + 1; w <= wcur; w++) T[w] = p;
-            if (p == r1 - 1)
-                for (int w = wcur + 1; w <= nbase; w++) T[w] = r1;
+        // a lane per table window: lower bound of the window's first column in the (sorted) row; the
+        // lanes of a wave search the same few cache lines and store consecutive table entries
+        for (int w = lane; w <= nbase; w += 64) {
+            int lo = r0, hi = r1;
+            if (w == nbase) lo = r1;
+            const int target = w < nbase ? w << shift : 0;
+            while (lo < hi) {
+                const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+                if (b_ix[mid] < target) lo = mid + 1;
+                else hi = mid;
+            }
+            T[w] = lo;
         }
     }
 }
