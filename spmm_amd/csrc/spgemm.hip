@@ -1331,11 +1331,13 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
 // SYM_COLS columns per pass (a whole row of C for matrices up to that width), a product costs one
 // 4-byte load and one ds_or_b32, and the row count is the popcount of the bitmap.
 constexpr int SYM_COLS = 1 << 20;
-static_assert(SYM_COLS / 1024 <= (1 << WIN_SHIFT_MIN), "a thread's share of the bitmap stays inside one table window");
 
+// Column lc of the pass is bit lc / WORDS of word lc % WORDS: the consecutive columns that the lanes of a
+// wave mark when they walk one long segment of a row of B fall into consecutive words, i.e. distinct LDS
+// banks, instead of into the same word.
 __device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
     const unsigned lc = (unsigned)(col - cbase);
-    atomicOr(&bits[lc >> 5], 1u << (lc & 31));
+    atomicOr(&bits[lc & (SYM_COLS / 32 - 1)], 1u << (lc / (SYM_COLS / 32)));
 }
 
 template <int THREADS>
@@ -1411,6 +1413,22 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
         }
         __syncthreads();
         // count and clear: thread t owns words [WPT*t, WPT*(t+1))
+        if (slot >= 0) {
+            // entries of C per table window for the numeric phase: bit b of the thread's words covers columns
+            // b*WORDS + [WPT*t, WPT*(t+1)), which lie inside one table window for all threads of a wave
+            static_assert(WORDS % (64 * WPT) == 0 && (64 * WPT) <= (1 << WIN_SHIFT_MIN), "a wave's words stay inside a table window");
+            for (int b = 0; b < 32; b++) {
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < WPT / 4; j++) {
+                    const uint4 x = ((const uint4*)bits)[tid * (WPT / 4) + j];
+                    c += ((x.x >> b) & 1u) + ((x.y >> b) & 1u) + ((x.z >> b) & 1u) + ((x.w >> b) & 1u);
+                }
+                c = wave_reduce_sum(c);
+                const int w = w0 + (int)(((unsigned)b * WORDS + (unsigned)tid * WPT) >> shift);
+                if (lane == 0 && c) atomicAdd(&wcnt[(int64_t)slot * nbase + w], (uint32_t)c);
+            }
+        }
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < WPT / 4; j++) {
@@ -1419,8 +1437,6 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
             if (cj) ((uint4*)bits)[tid * (WPT / 4) + j] = make_uint4(0u, 0u, 0u, 0u);
             cnt += cj;
         }
-        // the thread's 32*WPT columns lie inside one table window (windows have at least 2^14 columns)
-        if (slot >= 0 && cnt) atomicAdd(&wcnt[(int64_t)slot * nbase + w0 + ((tid * (32 * WPT)) >> shift)], (uint32_t)cnt);
         cnt = wave_reduce_sum(cnt);
         if (lane == 0 && cnt) atomicAdd(&tmp[0], cnt);
         __syncthreads();
