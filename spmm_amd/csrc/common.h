@@ -68,7 +68,7 @@ struct spmm_ctx {
     int giant_tasks = 16, giant_chunk = 1;   // workgroups per split row; consecutive table windows per turn
     int giant_len = 8192;   // dense rows with more entries of A than this are the ones that get split
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
-    long long dense_min = 1 << 18;   // rows with at least this many intermediate products use k_dense; 0 = off
+    long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse

@@ -14,7 +14,7 @@
 //                            position of B row k with column >= w << shift, so the part of a B
 //                            row inside a column window costs two loads and no search.
 //       symbolic             k_symd: LDS bitmap of 2^20 columns, one ds_or per product
-//       numeric, P_i >= dense_min (2^18)
+//       numeric, P_i >= dense threshold (3072 products per table window)
 //                            k_dense: dense fp64 accumulators for 2^14 columns + flag bytes
 //       numeric, below       k_win: bitmap + popcount rank prefix + compact fp64 accumulators
 //                            per window of up to 2^18 columns; windows of at most 8192 products
@@ -1500,16 +1500,24 @@ struct Bins {
 // gives at most 1024 windows, wider beyond; 2^15 columns and at most 256 windows when the dense
 // kernel is switched off.
 int table_shift(int32_t ncolB, long long dense_min) {
-    int shift = dense_min > 0 ? WIN_SHIFT_MIN : 15;
-    const int max_windows = dense_min > 0 ? 1024 : 256;
+    int shift = dense_min != 0 ? WIN_SHIFT_MIN : 15;
+    const int max_windows = dense_min != 0 ? 1024 : 256;
     while (shift < WIN_SHIFT_MAX && (((int64_t)ncolB + (1ll << shift) - 1) >> shift) > max_windows) shift++;
     return shift;
 }
 
-// rows with at least dense_min intermediate products use dense accumulators
-long long dense_threshold(const spmm_ctx* ctx) {
-    if (ctx->dense_min <= 0) return 0x7fffffffffffffffll;
-    return ctx->dense_min > 0xffffffffll ? 0xffffffffll : ctx->dense_min;   // the sort key of the row order saturates there
+// Rows with at least this many intermediate products use dense accumulators.  The dense kernel pays per
+// (entry of A, table window) pair, the cursor kernel per product, so the break-even grows with the number
+// of table windows: 3072 products per window measured on R-MAT scales 19..22 (32..256 windows), not below
+// 2^16.  dense_min > 0 fixes the threshold, 0 switches the dense kernel off.
+long long dense_threshold(const spmm_ctx* ctx, int nbase) {
+    if (ctx->dense_min == 0) return 0x7fffffffffffffffll;
+    long long d = ctx->dense_min;
+    if (d < 0) {
+        d = 3072ll * nbase;
+        if (d < 65536) d = 65536;
+    }
+    return d > 0xffffffffll ? 0xffffffffll : d;   // the sort key of the row order saturates there
 }
 
 int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, bool fresh,
@@ -1558,7 +1566,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
                            B->indices, counters);
     }
     int32_t nr = row_end - row_beg;
-    const long long dense_thr = dense_threshold(ctx);
+    const long long dense_thr = dense_threshold(ctx, out->nbase);
     // the symbolic call numbers the giant rows; a numeric call on the same matrices splits them when the
     // symbolic kernel left their per-window counts
     const bool can_count = ctx->split_giant && ctx->sym_cfg == 0 && out->shift <= 20 && out->nbase >= 2 * ctx->giant_tasks * ctx->giant_chunk &&
@@ -1732,7 +1740,7 @@ extern "C" int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shi
     if (nb < 1) nb = 1;
     if (shift) *shift = sh;
     if (nbase) *nbase = nb;
-    if (dense_min_products) *dense_min_products = dense_threshold(ctx);
+    if (dense_min_products) *dense_min_products = dense_threshold(ctx, nb);
     return SPMM_OK;
 }
 
