@@ -60,10 +60,10 @@ def product_balanced_bounds(prod, world):
 
 
 # Measured cost of one intermediate product by the kernel class of its row (ns per product on one
-# MI355X at R-MAT scale 22, symbolic + numeric): the dense-accumulator rows run at ~102 products/ns,
-# the window rows below them at ~108, the expand-sort-compress rows at ~34; the symbolic pass adds
+# MI355X at R-MAT scale 22, symbolic + numeric): the dense-accumulator rows and the window rows
+# below them both run at ~120 products/ns (the threshold between them is their break-even), the expand-sort-compress rows at ~34; the symbolic pass adds
 # ~1/500 for window rows and ~1/72 for the sorted rows.  Only the ratios matter.
-COST_NS = {"dense": 1 / 102 + 1 / 500, "window": 1 / 108 + 1 / 500, "sorted": 1 / 34 + 1 / 72}
+COST_NS = {"dense": 1 / 120 + 1 / 540, "window": 1 / 120 + 1 / 540, "sorted": 1 / 34 + 1 / 72}
 
 
 def cost_balanced_bounds(prod, world, sorted_max, dense_min):
