@@ -1330,7 +1330,10 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
 // Symbolic phase for window rows with the same barrier-free tiered sweep: the bitmap covers
 // SYM_COLS columns per pass (a whole row of C for matrices up to that width), a product costs one
 // 4-byte load and one ds_or_b32, and the row count is the popcount of the bitmap.
-constexpr int SYM_COLS = 1 << 20;
+#ifndef SYM_COLS_LOG2
+#define SYM_COLS_LOG2 20
+#endif
+constexpr int SYM_COLS = 1 << SYM_COLS_LOG2;
 
 // Column lc of the pass is bit lc / WORDS of word lc % WORDS: the consecutive columns that the lanes of a
 // wave mark when they walk one long segment of a row of B fall into consecutive words, i.e. distinct LDS
@@ -1401,13 +1404,26 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
                 mask_c &= mask_c - 1;
                 const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
                 const int rr = __builtin_amdgcn_readlane(rem, src);
-                for (int i = lane; i < rr; i += 512) {
-                    int cq[8];
+                // 512 products per turn; the loads of the next turn are issued before the marks of this one
+                // (unconditional loads: lanes past the end repeat the last product and do not mark)
+                int cq[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) cq[q] = i + 64 * q < rr ? b_ix[ss + i + 64 * q] : -1;
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * q;
+                    cq[q] = b_ix[ss + (i < rr ? i : rr - 1)];
+                }
+                for (int i0 = 0; i0 < rr; i0 += 512) {
+                    int nq[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int i = i0 + 512 + lane + 64 * q;
+                        nq[q] = b_ix[ss + (i < rr ? i : rr - 1)];
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; q++)
-                        if (i + 64 * q < rr) sym_mark(bits, cq[q], cbase);
+                        if (i0 + lane + 64 * q < rr) sym_mark(bits, cq[q], cbase);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) cq[q] = nq[q];
                 }
             }
         }
