@@ -1225,18 +1225,31 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
                     const int rr = __builtin_amdgcn_readlane(rem, src);
                     const double aa = readlane_f64(a, src);
-                    for (int i0 = 0; i0 < rr; i0 += 256) {   // wave-uniform trip count, unconditional loads
-                        int cq[4];
-                        double bq[4];
+                    // 256 products per turn, the loads of the next turn issued before the adds of this one
+                    // (wave-uniform trip count, unconditional loads: lanes past the end repeat the last product)
+                    int cq[4];
+                    double bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = 64 * q + lane;
+                        const int ic = i < rr ? i : rr - 1;
+                        bq[q] = b_val[ss + ic];
+                        cq[q] = b_ix[ss + ic];
+                    }
+                    for (int i0 = 0; i0 < rr; i0 += 256) {
+                        int cn[4];
+                        double bn[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const int i = i0 + 64 * q + lane;
-                            const int ic = i < rr ? i : rr - 1;          // lanes past the end repeat the last product
-                            bq[q] = b_val[ss + ic];
-                            cq[q] = b_ix[ss + ic];
+                            const int i = i0 + 256 + 64 * q + lane;
+                            const int ic = i < rr ? i : rr - 1;
+                            bn[q] = b_val[ss + ic];
+                            cn[q] = b_ix[ss + ic];
                         }
 #pragma unroll
                         for (int q = 0; q < 4; q++) dense_add(acc, flags, cq[q], cbase, aa * bq[q], i0 + 64 * q + lane < rr);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { cq[q] = cn[q]; bq[q] = bn[q]; }
                     }
                 }
             }
