@@ -989,10 +989,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // any is used.  wmap (256 bytes, private to the wave) maps a product of the batch to the lane
 // that holds its entry: entries mark the place where they start, a running maximum fills the
 // gaps.  act(col, a*b, valid) is called for every lane slot, valid for the products; b_val is
-// only read when WITH_VAL.
-template <bool WITH_VAL, typename F>
+// only read when WITH_VAL.  between() is called exactly once, after the loads of the first batch
+// have been issued (or at the end when there is no batch): work of the caller that consumes
+// earlier loads goes there, so that those and the batch's loads are in flight together.
+template <bool WITH_VAL, typename F, typename G>
 __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
-                                                int rem, double a, int lane, uint8_t* wmap, F&& act) {
+                                                int rem, double a, int lane, uint8_t* wmap, F&& act, G&& between) {
     uint32_t* wmap4 = (uint32_t*)wmap;
     rem = rem > 0 ? rem : 0;
     int inc = rem;
@@ -1052,9 +1054,11 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
             bq[j] = WITH_VAL ? b_val[pos] : 0.0;              // value first: the wait for the column covers it
             cq[j] = b_ix[pos];
         }
+        if (b0 == 0) between();
 #pragma unroll
         for (int j = 0; j < 4; j++) act(cq[j], aq[j] * bq[j], b0 + j * 64 + lane < R);
     }
+    if (R <= 0) between();
 }
 
 // 16-byte stores to addresses that are only element aligned (the compiler splits such a store; the hardware
@@ -1217,7 +1221,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 unsigned long long mask_c = __ballot(rem > 256);
                 // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
                 wave_flat_sweep<true>(b_ix, b_val, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
-                                      [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); });
+                                      [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); }, [] {});
                 // tier 3: the whole wave on one entry
                 while (mask_c) {
                     const int src = __ffsll(mask_c) - 1;
@@ -1398,19 +1402,20 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
                 s = Tq[w0];
                 len = Tq[w1] - s;
             }
-            // tier 1: products pi and pi+LA of the lane's own entry
-            {
-                const bool v0 = pi < len, v1 = pi + LA < len;
-                const int q0 = v0 ? b_ix[s + pi] : 0;
-                const int q1 = v1 ? b_ix[s + pi + LA] : 0;
-                if (v0) sym_mark(bits, q0, cbase);
-                if (v1) sym_mark(bits, q1, cbase);
-            }
+            // tier 1: products pi and pi+LA of the lane's own entry (unconditional loads, position 0 when
+            // there is no such product); marked once the loads of tier 2's first batch are on their way
+            const bool v0 = pi < len, v1 = pi + LA < len;
+            const int q0 = b_ix[v0 ? s + pi : 0];
+            const int q1 = b_ix[v1 ? s + pi + LA : 0];
             const int rem = lane < E ? len - 2 * LA : 0;
             unsigned long long mask_c = __ballot(rem > 256);
             // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
             wave_flat_sweep<false>(b_ix, nullptr, s + 2 * LA, rem <= 256 ? rem : 0, 0.0, lane, wmap,
-                                   [&](int col, double, bool valid) { if (valid) sym_mark(bits, col, cbase); });
+                                   [&](int col, double, bool valid) { if (valid) sym_mark(bits, col, cbase); },
+                                   [&] {
+                                       if (v0) sym_mark(bits, q0, cbase);
+                                       if (v1) sym_mark(bits, q1, cbase);
+                                   });
             // tier 3: the whole wave on one entry
             while (mask_c) {
                 const int src = __ffsll(mask_c) - 1;
