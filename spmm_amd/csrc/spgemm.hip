@@ -1042,21 +1042,25 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
         v3 = v3 > before ? v3 : before;
         wmap4[lane] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
         wave_sync_lds();   // the filled map of the other lanes
-        int cq[4];
-        double bq[4], aq[4];
+        int cq[4], sq[4];
+        double bq[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int q = b0 + j * 64 + lane;
             const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last product
-            const int src = (int)wmap[qc - b0] - 1;
-            const int pos = __shfl(so, src, 64) + qc;
-            aq[j] = WITH_VAL ? __shfl(a, src, 64) : 0.0;
+            sq[j] = (int)wmap[qc - b0] - 1;
+            const int pos = __shfl(so, sq[j], 64) + qc;
             bq[j] = WITH_VAL ? b_val[pos] : 0.0;              // value first: the wait for the column covers it
             cq[j] = b_ix[pos];
         }
         if (b0 == 0) between();
+        // the entry's value of A is fetched while the loads are in flight (holding the source lane costs
+        // one register per product, the value two)
 #pragma unroll
-        for (int j = 0; j < 4; j++) act(cq[j], aq[j] * bq[j], b0 + j * 64 + lane < R);
+        for (int j = 0; j < 4; j++) {
+            const double aj = WITH_VAL ? __shfl(a, sq[j], 64) : 0.0;
+            act(cq[j], aj * bq[j], b0 + j * 64 + lane < R);
+        }
     }
     if (R <= 0) between();
 }
@@ -1204,24 +1208,26 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     }
                 }
                 if (__ballot(len > 0) == 0ull) continue;   // nothing of this wave's entries falls into the window
-                // tier 1: products pi and pi+LA of the lane's own entry
-                if (pipelined) {
-                    dense_add(acc, flags, pc0, cbase, a * pb0, pi < len);
-                    dense_add(acc, flags, pc1, cbase, a * pb1, pi + LA < len);
-                } else {
-                    // unconditional loads (position 0 when there is no such product)
-                    const bool v0 = pi < len, v1 = pi + LA < len;
+                // tier 1: products pi and pi+LA of the lane's own entry: loaded a window ahead (pipelined rows)
+                // or here (unconditional loads, position 0 when there is no such product), and added once the
+                // loads of tier 2's first batch are on their way
+                const bool v0 = pi < len, v1 = pi + LA < len;
+                int q0 = pc0, q1 = pc1;
+                double r0 = pb0, r1 = pb1;
+                if (!pipelined) {
                     const int p0 = v0 ? s + pi : 0, p1 = v1 ? s + pi + LA : 0;
-                    const double r0 = b_val[p0], r1 = b_val[p1];
-                    const int q0 = b_ix[p0], q1 = b_ix[p1];
-                    dense_add(acc, flags, q0, cbase, a * r0, v0);
-                    dense_add(acc, flags, q1, cbase, a * r1, v1);
+                    r0 = b_val[p0]; r1 = b_val[p1];
+                    q0 = b_ix[p0]; q1 = b_ix[p1];
                 }
                 const int rem = lane < E ? len - 2 * LA : 0;
                 unsigned long long mask_c = __ballot(rem > 256);
                 // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
                 wave_flat_sweep<true>(b_ix, b_val, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
-                                      [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); }, [] {});
+                                      [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); },
+                                      [&] {
+                                          dense_add(acc, flags, q0, cbase, a * r0, v0);
+                                          dense_add(acc, flags, q1, cbase, a * r1, v1);
+                                      });
                 // tier 3: the whole wave on one entry
                 while (mask_c) {
                     const int src = __ffsll(mask_c) - 1;
