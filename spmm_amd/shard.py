@@ -59,18 +59,20 @@ def product_balanced_bounds(prod, world):
     return bounds
 
 
-# Measured cost of one intermediate product by the kernel class of its row (ns per product on one
-# MI355X at R-MAT scale 22, symbolic + numeric): the dense-accumulator rows and the window rows
-# below them both run at ~120 products/ns (the threshold between them is their break-even), the expand-sort-compress rows at ~34; the symbolic pass adds
-# ~1/500 for window rows and ~1/72 for the sorted rows.  Only the ratios matter.
-COST_NS = {"dense": 1 / 120 + 1 / 540, "window": 1 / 120 + 1 / 540, "sorted": 1 / 34 + 1 / 72}
+# Cost model of a row shard, fitted to the measured times (symbolic + numeric) of the shards of 4- and
+# 8-rank partitions of R-MAT scale 22 on one MI355X (tools/shard_balance.py; fit within 5 %): ns per
+# intermediate product by the kernel class of its row, plus a cost per row (one workgroup each, whatever
+# the class).  The sorted rows are an order of magnitude dearer per product than the window rows.
+# Only the ratios matter.
+COST_NS = {"dense": 0.0096, "window": 0.0073, "sorted": 0.102}
+ROW_NS = 10.2
 
 
 def cost_balanced_bounds(prod, world, sorted_max, dense_min):
     """Row boundaries like product_balanced_bounds, with every row's products weighted by the cost
     of its kernel class (rows with at most sorted_max products are sorted, rows with at least
-    dense_min use dense accumulators), so that the ranks finish together and not merely hold the
-    same number of products."""
+    dense_min use dense accumulators) plus a fixed cost per non-empty row, so that the ranks finish
+    together and not merely hold the same number of products."""
     n = prod.numel()
     if n == 0:
         return [0] * (world + 1)
@@ -78,7 +80,7 @@ def cost_balanced_bounds(prod, world, sorted_max, dense_min):
     w = torch.full_like(p, COST_NS["window"])
     w[prod <= sorted_max] = COST_NS["sorted"]
     w[prod >= dense_min] = COST_NS["dense"]
-    cum = torch.cumsum(p * w, 0)
+    cum = torch.cumsum(p * w + ROW_NS * (prod > 0).to(torch.float64), 0)
     total = float(cum[-1])
     bounds = [0]
     for r in range(1, world):

@@ -207,6 +207,20 @@ def test_product_rows_shared_by_workgroups(ctx):
     assert np.array_equal(ci, oi) and np.array_equal(cd, od)
 
 
+def test_plan_threshold_follows_window_count():
+    """Without SPMM_DENSE_MIN the dense kernel takes rows from 3072 products per table window of B (2^14
+    columns per window up to 1024 windows), and not below 2^16 products."""
+    c = capi.Context(0)
+    try:
+        assert c.plan_info(1 << 22) == (14, 256, 786432)
+        assert c.plan_info(1 << 20) == (14, 64, 196608)
+        assert c.plan_info(1000) == (14, 1, 65536)
+        shift, nbase, dmin = c.plan_info(1 << 27)
+        assert (shift, nbase, dmin) == (17, 1024, 3072 * 1024)
+    finally:
+        c.close()
+
+
 def test_product_rejects_unsorted_b(ctx):
     ip = np.array([0, 2, 3], np.int32)
     ix = np.array([1, 0, 1], np.int32)

@@ -93,6 +93,7 @@ def test_cost_balanced_bounds():
         assert b[0] == 0 and b[-1] == prod.numel() and all(x <= y for x, y in zip(b, b[1:]))
         p = prod.double()
         w = torch.where(prod <= 8192, shard.COST_NS["sorted"], torch.where(prod >= 262144, shard.COST_NS["dense"], shard.COST_NS["window"]))
-        cost = [float((p * w)[b[r]:b[r + 1]].sum()) for r in range(world)]
-        assert max(cost) - min(cost) <= 2 * float((p * w).max())          # balanced up to a row or two
+        c = p * w + shard.ROW_NS * (prod > 0).double()
+        cost = [float(c[b[r]:b[r + 1]].sum()) for r in range(world)]
+        assert max(cost) - min(cost) <= 2 * float(c.max())          # balanced up to a row or two
     assert shard.cost_balanced_bounds(torch.zeros(0, dtype=torch.int64), 3, 8192, 262144) == [0, 0, 0, 0]
