@@ -202,9 +202,9 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
 // span (the window kernels pay per column window, and a light row of a wide matrix has few
 // products in each).  Products are expanded as (column id, index); the pairs go through a stable
 // LSD radix sort on 8-bit digits (per wave: ranks by ballot match and digit counters in LDS; per
-// workgroup: one scan over [digit][wave]); equal columns end adjacent in product order, so the
-// sums add in the order of the serial algorithm.  Values are not carried through the sort: the
-// compress step reads a*b through the sorted index (position in B and entry of A per product).
+// workgroup: one scan over [digit][wave]); equal columns end adjacent.  Values are not carried
+// through the sort: the compress step reads a*b through the sorted index (position in B and entry
+// of A per product).
 template <int THREADS, int CAP, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                   const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
@@ -354,20 +354,58 @@ __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ li
     int total;
     int r = block_exclusive_scan<THREADS, int32_t>(heads, tmp, &total);
     if (NUMERIC) {
+        // Every thread fetches the EPT products of its own sorted positions (independent gathers, all in
+        // flight together) and sums the runs that start in its range; what precedes its first run head
+        // continues a run of an earlier thread, which collects those leading sums through LDS.
+        double* lead = (double*)cnt;                   // THREADS sums; the digit counters are free now
+        uint8_t* has_head = (uint8_t*)(lead + THREADS);
+        static_assert((size_t)THREADS * 9 <= (size_t)NW * 512 + (size_t)QCAP * 16, "leading sums fit the counters and the queue");
+        double v[EPT];
+        uint32_t key[EPT];
+        bool hd[EPT];
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
             const int i = tid * EPT + j;
-            if (i < N && (i == 0 || ks[i - 1] != ks[i])) {
-                const uint32_t key = ks[i];
-                double sum = 0.0;
-                for (int u = i; u < N && ks[u] == key; u++) {
-                    const int q = is[u];
-                    sum += a_val[a0 + pent[q]] * b_val[ppos[q]];
+            const int ic = i < N ? i : 0;
+            const int q = N > 0 ? is[ic] : 0;
+            key[j] = ks[ic];
+            hd[j] = i < N && (i == 0 || ks[ic - (i > 0 ? 1 : 0)] != key[j]);
+            v[j] = N > 0 ? a_val[a0 + pent[q]] * b_val[ppos[q]] : 0.0;
+        }
+        double lsum = 0.0, cur = 0.0;
+        uint32_t cur_key = 0;
+        bool open = false;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int i = tid * EPT + j;
+            if (i < N) {
+                if (hd[j]) {
+                    if (open) {
+                        c_ix[obase + r] = (int32_t)cur_key;
+                        c_val[obase + r] = cur;
+                        r++;
+                    }
+                    open = true;
+                    cur = v[j];
+                    cur_key = key[j];
+                } else if (open) {
+                    cur += v[j];
+                } else {
+                    lsum += v[j];
                 }
-                c_ix[obase + r] = (int32_t)key;
-                c_val[obase + r] = sum;
-                r++;
             }
+        }
+        lead[tid] = lsum;
+        has_head[tid] = open ? 1 : 0;
+        __syncthreads();
+        if (open) {
+            // the thread's last run may go on in the ranges of the next threads
+            for (int t = tid + 1; t < THREADS && t * EPT < N; t++) {
+                cur += lead[t];
+                if (has_head[t]) break;
+            }
+            c_ix[obase + r] = (int32_t)cur_key;
+            c_val[obase + r] = cur;
         }
     } else if (tid == 0) {
         rowcnt[row] = total;

@@ -207,6 +207,37 @@ def test_product_rows_shared_by_workgroups(ctx):
     assert np.array_equal(ci, oi) and np.array_equal(cd, od)
 
 
+def test_product_sorted_rows_with_many_empty_b_rows(ctx):
+    """Rows of A with thousands of entries but at most 8192 products (most of the rows of B they name are
+    empty): the expand step of the sorting kernels walks many chunks of entries that add nothing."""
+    rng = np.random.default_rng(5)
+    kb, ncol = 30000, 70000
+    b_len = np.zeros(kb, np.int64)
+    full = rng.choice(kb, 600, replace=False)
+    b_len[full] = rng.integers(1, 90, full.size)
+    b_ip = np.zeros(kb + 1, np.int32)
+    b_ip[1:] = np.cumsum(b_len)
+    b_ix = np.concatenate([np.sort(rng.choice(ncol, l, replace=False)) for l in b_len if l]).astype(np.int32)
+    b_d = rng.integers(1, 4, b_ix.size).astype(np.float64)
+    a_rows = []
+    for nent, nfull in [(9000, 120), (5000, 100), (3000, 60), (700, 100), (12000, 5), (200, 0)]:
+        ent = np.concatenate([rng.choice(full, nfull, replace=False), rng.choice(np.setdiff1d(np.arange(kb), full), nent - nfull, replace=False)])
+        a_rows.append(np.sort(ent))
+    a_ip = np.zeros(len(a_rows) + 1, np.int32)
+    a_ip[1:] = np.cumsum([r.size for r in a_rows])
+    a_ix = np.concatenate(a_rows).astype(np.int32)
+    a_d = rng.integers(1, 4, a_ix.size).astype(np.float64)
+    prod, _ = orc.row_products(a_ip, a_ix, b_ip)
+    assert prod.max() <= 8192 and prod[0] > 512 and prod[-1] == 0
+    A, B = capi.Csr(len(a_rows), kb, a_ip, a_ix, a_d), capi.Csr(kb, ncol, b_ip, b_ix, b_d)
+    c_ip, nnz_c, prods = ctx.spgemm_symbolic(A, B)
+    o_ip = orc.spgemm_symbolic(len(a_rows), ncol, a_ip, a_ix, b_ip, b_ix)
+    assert np.array_equal(c_ip, o_ip) and prods == int(prod.sum())
+    ci, cd = ctx.spgemm_numeric(A, B, c_ip)
+    oi, od, _ = orc.spgemm_numeric(ncol, (a_ip, a_ix, a_d), (b_ip, b_ix, b_d), o_ip)
+    assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+
+
 def test_plan_threshold_follows_window_count():
     """Without SPMM_DENSE_MIN the dense kernel takes rows from 3072 products per table window of B (2^14
     columns per window up to 1024 windows), and not below 2^16 products."""
