@@ -1438,7 +1438,42 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
     for (int w0 = 0; w0 < nbase; w0 += mwin) {
         const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
         const int cbase = w0 << shift;
-        for (int c = 0; c < npass; c++) {
+        // Rows with at most 64 entries (most rows: a few entries that name long rows of B): every wave
+        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
+        // the chunks dealt round the waves, eight per turn and wave, so that all waves carry the same
+        // load whatever the lengths of the segments.
+        if (lenA <= 64) {
+            int s = 0, len = 0;
+            if (lane < lenA) {
+                const int32_t* Tq = winptr + (int64_t)a_ix[a0 + lane] * tstride;
+                s = Tq[w0];
+                len = Tq[w1] - s;
+            }
+            const int nch = (len + 63) >> 6;
+            const int inc = wave_inclusive_scan_i32(nch);
+            const int total = __builtin_amdgcn_readlane(inc, 63);
+            const int choff = inc - nch;
+            for (int j0 = wv; j0 < total; j0 += NW * 8) {
+                int cq[8];
+                bool ok[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int j = j0 + q * NW;
+                    const int jc = j < total ? j : total - 1;
+                    // the entry of chunk jc: the last one with chunks whose first chunk is not after jc
+                    const unsigned long long m = __ballot(nch > 0 && choff <= jc);
+                    const int e = 63 - __clzll((long long)m);
+                    const int se = __builtin_amdgcn_readlane(s, e), le = __builtin_amdgcn_readlane(len, e);
+                    const int i = (jc - __builtin_amdgcn_readlane(choff, e)) * 64 + lane;
+                    ok[q] = j < total && i < le;
+                    cq[q] = b_ix[se + (i < le ? i : le - 1)];   // unconditional load
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (ok[q]) sym_mark(bits, cq[q], cbase);
+            }
+        }
+        for (int c = 0; c < (lenA <= 64 ? 0 : npass); c++) {
             const int e = ((c << lgE) + el) * NW + wv;
             int s = 0, len = 0;
             if (e < lenA) {
