@@ -1404,6 +1404,9 @@ __device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
     atomicOr(&bits[lc & (SYM_COLS / 32 - 1)], 1u << (lc / (SYM_COLS / 32)));
 }
 
+#ifndef SYM_FEW
+#define SYM_FEW 64
+#endif
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                   const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
@@ -1438,14 +1441,15 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
     for (int w0 = 0; w0 < nbase; w0 += mwin) {
         const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
         const int cbase = w0 << shift;
-        // Rows with at most 64 entries (most rows: a few entries that name long rows of B): every wave
-        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
+        // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B), 64 entries
+        // at a time: every wave holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
         // the chunks dealt round the waves, eight per turn and wave, so that all waves carry the same
         // load whatever the lengths of the segments.
-        if (lenA <= 64) {
+        int rot = 0;   // wave that takes the next group's first chunk
+        for (int g = 0; g < (lenA <= SYM_FEW ? lenA : 0); g += 64) {
             int s = 0, len = 0;
-            if (lane < lenA) {
-                const int32_t* Tq = winptr + (int64_t)a_ix[a0 + lane] * tstride;
+            if (g + lane < lenA) {
+                const int32_t* Tq = winptr + (int64_t)a_ix[a0 + g + lane] * tstride;
                 s = Tq[w0];
                 len = Tq[w1] - s;
             }
@@ -1453,7 +1457,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
             const int inc = wave_inclusive_scan_i32(nch);
             const int total = __builtin_amdgcn_readlane(inc, 63);
             const int choff = inc - nch;
-            for (int j0 = wv; j0 < total; j0 += NW * 8) {
+            for (int j0 = (wv - rot + NW) & (NW - 1); j0 < total; j0 += NW * 8) {
                 int cq[8];
                 bool ok[8];
 #pragma unroll
@@ -1472,8 +1476,9 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
                 for (int q = 0; q < 8; q++)
                     if (ok[q]) sym_mark(bits, cq[q], cbase);
             }
+            rot = (rot + total) & (NW - 1);
         }
-        for (int c = 0; c < (lenA <= 64 ? 0 : npass); c++) {
+        for (int c = 0; c < (lenA <= SYM_FEW ? 0 : npass); c++) {
             const int e = ((c << lgE) + el) * NW + wv;
             int s = 0, len = 0;
             if (e < lenA) {
