@@ -1436,28 +1436,36 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 
     for (int i = tid; i < WORDS / 4; i += THREADS) ((uint4*)bits)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) tmp[0] = 0;
+    // few entries: lane e of every wave keeps entry e's table row and the bounds of the current pass
+    static_assert(SYM_FEW <= 64, "one entry per lane");
+    const bool few = lenA <= SYM_FEW;
+    const int32_t* Tf = winptr;
+    int f_lo = 0, f_hi = 0;
+    if (few && lane < lenA) {
+        Tf = winptr + (int64_t)a_ix[a0 + lane] * tstride;
+        f_lo = Tf[0];
+        f_hi = Tf[mwin < nbase ? mwin : nbase];
+    }
     __syncthreads();
 
     for (int w0 = 0; w0 < nbase; w0 += mwin) {
         const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
         const int cbase = w0 << shift;
-        // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B), 64 entries
-        // at a time: every wave holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
+        // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B): every wave
+        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
         // the chunks dealt round the waves, eight per turn and wave, so that all waves carry the same
-        // load whatever the lengths of the segments.
-        int rot = 0;   // wave that takes the next group's first chunk
-        for (int g = 0; g < (lenA <= SYM_FEW ? lenA : 0); g += 64) {
-            int s = 0, len = 0;
-            if (g + lane < lenA) {
-                const int32_t* Tq = winptr + (int64_t)a_ix[a0 + g + lane] * tstride;
-                s = Tq[w0];
-                len = Tq[w1] - s;
-            }
+        // load whatever the lengths of the segments.  The table bound of the next pass is loaded a pass
+        // ahead.
+        if (few) {
+            const int w2 = w1 + mwin < nbase ? w1 + mwin : nbase;
+            int f_nx = f_hi;
+            if (lane < lenA && w1 < nbase) f_nx = Tf[w2];
+            const int s = f_lo, len = f_hi - f_lo;
             const int nch = (len + 63) >> 6;
             const int inc = wave_inclusive_scan_i32(nch);
             const int total = __builtin_amdgcn_readlane(inc, 63);
             const int choff = inc - nch;
-            for (int j0 = (wv - rot + NW) & (NW - 1); j0 < total; j0 += NW * 8) {
+            for (int j0 = wv; j0 < total; j0 += NW * 8) {
                 int cq[8];
                 bool ok[8];
 #pragma unroll
@@ -1476,9 +1484,10 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
                 for (int q = 0; q < 8; q++)
                     if (ok[q]) sym_mark(bits, cq[q], cbase);
             }
-            rot = (rot + total) & (NW - 1);
+            f_lo = f_hi;
+            f_hi = f_nx;
         }
-        for (int c = 0; c < (lenA <= SYM_FEW ? 0 : npass); c++) {
+        for (int c = 0; c < (few ? 0 : npass); c++) {
             const int e = ((c << lgE) + el) * NW + wv;
             int s = 0, len = 0;
             if (e < lenA) {
