@@ -431,17 +431,36 @@ __global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __
         const int r0 = b_ip[k], r1 = b_ip[k + 1];
         int32_t* T = winptr + k * (int64_t)(nbase + 1);
         // a lane per table window: lower bound of the window's first column in the (sorted) row; the
-        // lanes of a wave search the same few cache lines and store consecutive table entries
-        for (int w = lane; w <= nbase; w += 64) {
-            int lo = r0, hi = r1;
-            if (w == nbase) lo = r1;
-            const int target = w < nbase ? w << shift : 0;
-            while (lo < hi) {
-                const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-                if (b_ix[mid] < target) lo = mid + 1;
-                else hi = mid;
+        // lanes of a wave store consecutive table entries.  Rows of at most 64 entries (nearly all) are
+        // held one entry per lane and searched by shuffles, so that a search step is not a trip to memory.
+        const int len = r1 - r0;
+        if (len <= 64) {
+            const int mine = lane < len ? b_ix[r0 + lane] : 0x7fffffff;
+            for (int w0 = 0; w0 <= nbase; w0 += 64) {   // all lanes stay in the loop: they are shuffle sources
+                const int w = w0 + lane;
+                const int target = w < nbase ? w << shift : 0x7fffffff;
+                int lo = 0;   // number of entries below the target: six halving steps over 64 slots
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int probe = __shfl(mine, lo + step - 1, 64);
+                    lo += probe < target ? step : 0;
+                }
+                const int last = __shfl(mine, 63, 64);
+                lo += (lo == 63 && last < target) ? 1 : 0;
+                if (w <= nbase) T[w] = r0 + (lo < len ? lo : len);
             }
-            T[w] = lo;
+        } else {
+            for (int w = lane; w <= nbase; w += 64) {
+                int lo = r0, hi = r1;
+                if (w == nbase) lo = r1;
+                const int target = w < nbase ? w << shift : 0;
+                while (lo < hi) {
+                    const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+                    if (b_ix[mid] < target) lo = mid + 1;
+                    else hi = mid;
+                }
+                T[w] = lo;
+            }
         }
     }
 }
