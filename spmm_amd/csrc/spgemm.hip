@@ -43,25 +43,48 @@ __device__ __forceinline__ void wave_sync_lds() {
 enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_N = 12 };
 
 // ---------------------------------------------------------------------------
-// P_i per row, one wave per row.
+// P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
+// by a whole wave afterwards.
 __global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrowB, const int32_t* __restrict__ a_ip,
                                                       const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ip,
                                                       int64_t* __restrict__ prod, long long* __restrict__ counters) {
-    const int lane = threadIdx.x & 63;
-    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < nrow; row += nw) {
-        int a0 = a_ip[row], a1 = a_ip[row + 1];
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int64_t ng = (int64_t)gridDim.x * (blockDim.x >> 4);
+    bool bad = false;
+    // a wave takes four consecutive rows per turn; the loop bound is the same for all its lanes
+    for (int64_t rowbase = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane) >> 4; rowbase < nrow; rowbase += ng) {
+        const int64_t row = rowbase + (lane >> 4);
+        const bool have = row < nrow;
+        const int a0 = have ? a_ip[row] : 0, a1 = have ? a_ip[row + 1] : 0;
+        const bool longrow = a1 - a0 > 4096;
         long long s = 0;
-        bool bad = false;
-        for (int p = a0 + lane; p < a1; p += 64) {
-            int k = a_ix[p];
-            if ((uint32_t)k >= (uint32_t)nrowB) { bad = true; continue; }
-            s += b_ip[k + 1] - b_ip[k];
+        if (!longrow)
+            for (int p = a0 + sub; p < a1; p += 16) {
+                const int k = a_ix[p];
+                if ((uint32_t)k >= (uint32_t)nrowB) { bad = true; continue; }
+                s += b_ip[k + 1] - b_ip[k];
+            }
+        // sum over the sixteen lanes of the row
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        // long rows of this wave's four groups: all 64 lanes, one row after the other
+        unsigned long long lm = __ballot(longrow && sub == 0);
+        while (lm) {
+            const int src = __ffsll(lm) - 1;
+            lm &= lm - 1;
+            const int b0 = __builtin_amdgcn_readlane(a0, src), b1 = __builtin_amdgcn_readlane(a1, src);
+            long long t = 0;
+            for (int p = b0 + lane; p < b1; p += 64) {
+                const int k = a_ix[p];
+                if ((uint32_t)k >= (uint32_t)nrowB) { bad = true; continue; }
+                t += b_ip[k + 1] - b_ip[k];
+            }
+            t = wave_reduce_sum(t);
+            if ((lane & ~15) == src) s = t;
         }
-        s = wave_reduce_sum(s);
-        if (lane == 0) prod[row] = s;
-        if (bad) counters[CNT_BAD] = 1;
+        if (have && sub == 0) prod[row] = s;
     }
+    if (bad) counters[CNT_BAD] = 1;
 }
 
 __global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol, const int32_t* __restrict__ ip,
@@ -1700,8 +1723,8 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     CHK(ws(ctx, WS_WINPTR, table_elems + 1, &out->winptr));
     HIPCHK(hipMemsetAsync(counters, 0, sizeof(long long) * CNT_N, ctx->stream));
     if (!hit && nrow > 0) {
-        int64_t nb = ((int64_t)nrow + 3) / 4;
-        if (nb > 256 * 32) nb = 256 * 32;
+        int64_t nb = ((int64_t)nrow + 15) / 16;
+        if (nb > 256 * 64) nb = 256 * 64;
         hipLaunchKernelGGL(k_row_products, dim3((unsigned)nb), dim3(256), 0, ctx->stream, nrow, B->nrow, A->indptr,
                            A->indices, B->indptr, out->prod, counters);
     }
