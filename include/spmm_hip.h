@@ -21,6 +21,7 @@
  */
 #ifndef SPMM_HIP_H
 #define SPMM_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -91,6 +92,24 @@ void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
  * *dense_min_products intermediate products take the dense-accumulator numeric kernel (INT64_MAX
  * when that kernel is switched off).  Diagnostic, no counterpart in the reference. */
 int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shift, int32_t* nbase, int64_t* dense_min_products);
+
+/* ---- MatrixMarket text: replaces the reading part of csr_matrix(),
+ *      serial_newblock_clock.cpp:47-104.  spmm_mtx_header (host only, no GPU) skips the leading '%'
+ *      lines (:50, :64), reads "nrow ncol nnz" (:65) and decides between two and three tokens per
+ *      entry by the reference's rule (:52-58, :80: two iff the line after the size line holds exactly
+ *      one ' ' byte; a tab-separated file therefore counts as three, as it does there);
+ *      *data_offset = first byte after the size line.  spmm_mtx_entries converts the entries on the GPU with the reference's token
+ *      rule (`fin >> row >> col [>> s]`, :86, :98: whitespace-separated tokens, line ends carry no
+ *      meaning, a third token is skipped unread, anything after nnz entries is ignored) into
+ *      zero-based row[nnz], col[nnz].  Where the reference reads garbage, this returns SPMM_E_ARG:
+ *      fewer than nnz entries, a row/column token that is not a decimal integer, a number outside
+ *      [1, 2^31-1].  The _dev variant takes device pointers; its text must be 16-byte aligned. */
+int spmm_mtx_header(const char* text, size_t bytes, int32_t* nrow, int32_t* ncol, int64_t* nnz, size_t* data_offset,
+                    int32_t* tokens_per_entry);
+int spmm_mtx_entries(spmm_ctx* ctx, const char* text, size_t bytes, size_t data_offset, int32_t tokens_per_entry,
+                     int64_t nnz, int32_t* row, int32_t* col);
+int spmm_mtx_entries_dev(spmm_ctx* ctx, const char* text, size_t bytes, size_t data_offset, int32_t tokens_per_entry,
+                         int64_t nnz, int32_t* row, int32_t* col);
 
 /* ---- CSR build: replaces the in-memory part of csr_matrix(),
  *      serial_newblock_clock.cpp:78-112 (row histogram, exclusive scan, scatter that keeps

@@ -64,6 +64,30 @@ def read_mtx(path):
     return nrow.value, ncol.value, row, col
 
 
+def mtx_tokens(text):
+    """Token-level restatement of the reader, serial_newblock_clock.cpp:47-104, on the bytes of a file:
+    leading '%' lines skipped (:50, :64); `fin >> num_row >> num_col >> num_lines` (:65); two or three
+    tokens per entry decided by the ' ' bytes of the line after the size line (:52-58, :80); then
+    `fin >> row >> col` (:86) or `fin >> row >> col >> s` (:98) num_lines times: whitespace-separated
+    tokens, line ends carry no meaning, what follows the last entry is not read.
+    Returns (nrow, ncol, row, col), zero-based int32."""
+    p = 0
+    while p < len(text) and text[p:p + 1] == b"%":
+        q = text.find(b"\n", p)
+        p = len(text) if q < 0 else q + 1
+    q = text.find(b"\n", p)
+    q = len(text) if q < 0 else q
+    nrow, ncol, nnz = (int(x) for x in text[p:q].split()[:3])
+    body = text[q + 1:]
+    per = 2 if body.split(b"\n", 1)[0].count(b" ") + 1 == 2 else 3     # :52-58, :80
+    tok = body.split()
+    if len(tok) < per * nnz:
+        raise ValueError("fewer tokens than entries")
+    row = np.array([int(t) for t in tok[0:per * nnz:per]], dtype=np.int64) - 1
+    col = np.array([int(t) for t in tok[1:per * nnz:per]], dtype=np.int64) - 1
+    return nrow, ncol, row.astype(I32), col.astype(I32)
+
+
 def csr_from_coo(nrow, row, col):
     row, col = _i32(row), _i32(col)
     nnz = row.size

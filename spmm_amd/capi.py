@@ -142,6 +142,21 @@ class Context:
     def last_kernel_ms(self):
         return float(lib().spmm_last_kernel_ms(self._h))
 
+    # ---- MatrixMarket text (serial_newblock_clock.cpp:47-104) ---------------
+    def mtx_parse(self, text):
+        """bytes of a MatrixMarket coordinate file -> (nrow, ncol, row, col), zero-based int32 arrays;
+        the header is read on the host, the entries are converted on the GPU."""
+        buf = bytes(text)
+        nrow, ncol, nnz, off, per = C.c_int32(), C.c_int32(), C.c_int64(), C.c_size_t(), C.c_int32()
+        _chk(lib().spmm_mtx_header(buf, C.c_size_t(len(buf)), C.byref(nrow), C.byref(ncol), C.byref(nnz), C.byref(off), C.byref(per)))
+        row, col = np.empty(nnz.value, I32), np.empty(nnz.value, I32)
+        _chk(lib().spmm_mtx_entries(self._h, buf, C.c_size_t(len(buf)), off, per, nnz, _p(row), _p(col)))
+        return nrow.value, ncol.value, row, col
+
+    def mtx_entries_dev(self, text_ptr, nbytes, data_offset, per, nnz, row_ptr, col_ptr):
+        _chk(lib().spmm_mtx_entries_dev(self._h, C.c_void_p(text_ptr), C.c_size_t(nbytes), C.c_size_t(data_offset), C.c_int32(per),
+                                        C.c_int64(nnz), C.c_void_p(row_ptr), C.c_void_p(col_ptr)))
+
     # ---- CSR build (serial_newblock_clock.cpp:78-112) ---------------------
     def csr_from_coo(self, nrow, ncol, row, col):
         row, col = _np(row, I32), _np(col, I32)

@@ -4,8 +4,8 @@
 //   -> result.txt, truncated at start, one line "<name> <ms>ms" per matrix (:510-512, :565)
 //   -> stdout "----name:<name>----" (:567); exit 1 with a message when result.txt cannot be
 //      opened (:513-516).
-// The in-memory work is done by libspmm_hip.so through its C ABI: spmm_csr_from_coo in place of
-// the tail of csr_matrix() (:78-112) and spmm_trace_formats in place of gen_trace_formats()
+// The work is done by libspmm_hip.so through its C ABI: spmm_mtx_header / spmm_mtx_entries in place of
+// the reading part of csr_matrix() (:47-104), spmm_csr_from_coo in place of its tail (:78-112) and spmm_trace_formats in place of gen_trace_formats()
 // (:221-499).  There is no CPU path: without a gfx950 GPU the program stops with an error.
 //
 // The time written to result.txt is the GPU time of the pipeline with the matrix resident in
@@ -34,48 +34,19 @@ std::string strip_name(const std::string& s) {   // serial_newblock_clock.cpp:36
     return out;
 }
 
-// MatrixMarket coordinate reader with the reference's semantics (serial_newblock_clock.cpp:47-104):
-// '%' lines skipped, "nrow ncol nnz", then nnz lines of which only the first two integers are used.
-bool read_mtx(const std::string& path, int& nrow, int& ncol, std::vector<int>& row, std::vector<int>& col) {
+// The bytes of a file, padded so that the library may read whole 16-byte words.
+bool read_file(const std::string& path, std::vector<char>& buf, size_t& bytes) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     std::fseek(f, 0, SEEK_END);
-    long sz = std::ftell(f);
+    const long sz = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)sz + 1);
-    if (sz > 0 && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); return false; }
+    if (sz < 0) { std::fclose(f); return false; }
+    bytes = (size_t)sz;
+    buf.assign(bytes + 16, ' ');
+    const bool ok = bytes == 0 || std::fread(buf.data(), 1, bytes, f) == bytes;
     std::fclose(f);
-    buf[(size_t)sz] = 0;
-    const char* p = buf.data();
-    const char* end = p + sz;
-    auto skip_line = [&]() { while (p < end && *p != '\n') p++; if (p < end) p++; };
-    while (p < end && *p == '%') skip_line();
-    auto next_int = [&](long long& v) -> bool {
-        while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
-        if (p >= end || *p == '\n') return false;
-        bool neg = false;
-        if (*p == '-') { neg = true; p++; }
-        if (p >= end || *p < '0' || *p > '9') return false;
-        long long x = 0;
-        while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); p++; }
-        v = neg ? -x : x;
-        return true;
-    };
-    long long a, b, c;
-    if (!next_int(a) || !next_int(b) || !next_int(c)) return false;
-    skip_line();
-    nrow = (int)a; ncol = (int)b;
-    row.resize((size_t)c);
-    col.resize((size_t)c);
-    for (long long l = 0; l < c; l++) {
-        while (p < end && (*p == '\n' || *p == '\r')) p++;
-        long long r, cc;
-        if (!next_int(r) || !next_int(cc)) return false;
-        skip_line();
-        row[(size_t)l] = (int)(r - 1);
-        col[(size_t)l] = (int)(cc - 1);
-    }
-    return true;
+    return ok;
 }
 
 #define CK(call)                                                              \
@@ -92,9 +63,21 @@ bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, st
     int nrow = 0, ncol = 0;
     std::vector<int> row, col;
     auto t0 = std::chrono::high_resolution_clock::now();
-    if (!read_mtx(path, nrow, ncol, row, col)) {
-        std::cerr << "cannot read " << path << "\n";
-        return false;
+    {
+        // MatrixMarket text -> entries (serial_newblock_clock.cpp:47-104): header on the host,
+        // the entries on the GPU
+        std::vector<char> text;
+        size_t bytes = 0, data_offset = 0;
+        if (!read_file(path, text, bytes)) {
+            std::cerr << "cannot read " << path << "\n";
+            return false;
+        }
+        int64_t nz = 0;
+        int per = 2;
+        CK(spmm_mtx_header(text.data(), bytes, &nrow, &ncol, &nz, &data_offset, &per));
+        row.resize((size_t)nz);
+        col.resize((size_t)nz);
+        CK(spmm_mtx_entries(ctx, text.data(), bytes, data_offset, per, nz, row.data(), col.data()));
     }
     auto t1 = std::chrono::high_resolution_clock::now();
     const int nnz = (int)row.size();

@@ -26,9 +26,8 @@ def _workdir(tmp_path, names):
 
 
 def test_harness_is_built_and_refuses_to_run_without_a_gpu(tmp_path):
-    import torch
     assert os.path.exists(SERIAL), "build first: make -C spmm_amd/harness"
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")
     _workdir(tmp_path, {"tiny": (50,) + synth.uniform(50, 200, 1)})
     r = subprocess.run([SERIAL], cwd=tmp_path, capture_output=True, text=True, timeout=120)
