@@ -12,10 +12,14 @@
 // device memory (hipEvents around the stages), the counterpart of the reference's sum of stage
 // timers, which starts with the matrix resident in host memory.  With SPMM_HARNESS_SPGEMM=1 the
 // product C = A*A is computed as well and one JSON line per matrix goes to result_spgemm.txt.
+// With SPMM_HARNESS_TRACE=<dir> every array of the pipeline, the per-block formats included (which
+// the reference computes and drops, :221 by-value parameters, :363), is written to
+// <dir>/<name>/<array>.npy (NumPy format 1.0, little endian, C order).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -47,6 +51,21 @@ bool read_file(const std::string& path, std::vector<char>& buf, size_t& bytes) {
     const bool ok = bytes == 0 || std::fread(buf.data(), 1, bytes, f) == bytes;
     std::fclose(f);
     return ok;
+}
+
+// One array as a .npy file (format 1.0: magic, version, header length, a dict padded to 64 bytes).
+template <typename T>
+bool write_npy(const std::string& path, const T* a, size_t n, const char* descr) {
+    std::string h = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': (" + std::to_string(n) + ",), }";
+    while ((10 + h.size() + 1) % 64 != 0) h.push_back(' ');
+    h.push_back('\n');
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    const unsigned char len[2] = {(unsigned char)(h.size() & 255), (unsigned char)(h.size() >> 8)};
+    bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(len, 1, 2, f) == 2 && std::fwrite(h.data(), 1, h.size(), f) == h.size();
+    ok = ok && (n == 0 || std::fwrite(a, sizeof(T), n, f) == n);
+    return std::fclose(f) == 0 && ok;
 }
 
 #define CK(call)                                                              \
@@ -98,6 +117,21 @@ bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, st
     tr.rseq = rseq.data();
     tr.bsize_list = bsize.data();
     tr.seq_offset = seq_offset.data();
+    // the on-disk trace wants every array (sizes as documented for spmm_trace)
+    const char* trace_dir = std::getenv("SPMM_HARNESS_TRACE");
+    const size_t npan = (size_t)nrow / 8 + 3 * (size_t)cap + 8;
+    std::vector<int> seq_bitmap, r_indptr, r_indices, panel_ptr, panel_list, spv8_list, out_seq_all, b_indptr, b_colidx_orig, b_local, keys;
+    std::vector<double> r_data, b_data;
+    if (trace_dir) {
+        seq_bitmap.resize((size_t)nrow + 1); r_indptr.resize((size_t)nrow + 1); r_indices.resize((size_t)nnz + 1); r_data.resize((size_t)nnz + 1);
+        panel_ptr.resize((size_t)cap + 1); panel_list.resize(npan); spv8_list.resize(npan); out_seq_all.resize((size_t)nrow + 1);
+        b_indptr.resize((size_t)nrow + cap + 1); b_colidx_orig.resize((size_t)nnz + 1); b_local.resize((size_t)nnz + 1);
+        b_data.resize((size_t)nnz + 1); keys.resize((size_t)nnz + 1);
+        tr.seq_bitmap = seq_bitmap.data(); tr.r_indptr = r_indptr.data(); tr.r_indices = r_indices.data(); tr.r_data = r_data.data();
+        tr.panel_ptr = panel_ptr.data(); tr.panel_list = panel_list.data(); tr.spv8_list = spv8_list.data();
+        tr.out_seq_all = out_seq_all.data(); tr.b_indptr = b_indptr.data(); tr.b_colidx_orig = b_colidx_orig.data();
+        tr.b_local = b_local.data(); tr.b_data = b_data.data(); tr.keys = keys.data();
+    }
     auto t2 = std::chrono::high_resolution_clock::now();
     CK(spmm_trace_formats(ctx, &A, 2048, 512 * 1024 / 8, &tr));
     auto t3 = std::chrono::high_resolution_clock::now();
@@ -107,6 +141,28 @@ bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, st
 
     outfile << mname << " " << ms_gpu << "ms" << std::endl;
     std::cout << "----name:" << mname << "----" << std::endl;
+
+    if (trace_dir) {
+        const std::string d = std::string(trace_dir) + "/" + mname;
+        std::error_code ec;
+        std::filesystem::create_directories(d, ec);
+        const size_t nb = (size_t)tr.bnum, nk = (size_t)tr.n_keys, z = (size_t)nnz, nr = (size_t)nrow;
+        bool ok = !ec;
+        ok = ok && write_npy(d + "/seq_bitmap.npy", seq_bitmap.data(), nr, "<i4") && write_npy(d + "/r_indptr.npy", r_indptr.data(), nr + 1, "<i4");
+        ok = ok && write_npy(d + "/r_indices.npy", r_indices.data(), z, "<i4") && write_npy(d + "/r_data.npy", r_data.data(), z, "<f8");
+        ok = ok && write_npy(d + "/bsize_list.npy", bsize.data(), nb + 1, "<i4") && write_npy(d + "/seq_offset.npy", seq_offset.data(), nb + 1, "<i4");
+        ok = ok && write_npy(d + "/panel_ptr.npy", panel_ptr.data(), nb + 1, "<i4");
+        ok = ok && write_npy(d + "/panel_list.npy", panel_list.data(), (size_t)tr.n_panel_entries, "<i4");
+        ok = ok && write_npy(d + "/spv8_list.npy", spv8_list.data(), (size_t)tr.n_spv8, "<i4");
+        ok = ok && write_npy(d + "/out_seq_all.npy", out_seq_all.data(), nr, "<i4") && write_npy(d + "/b_indptr.npy", b_indptr.data(), nr + nb, "<i4");
+        ok = ok && write_npy(d + "/b_colidx_orig.npy", b_colidx_orig.data(), z, "<i4") && write_npy(d + "/b_local.npy", b_local.data(), z, "<i4");
+        ok = ok && write_npy(d + "/b_data.npy", b_data.data(), z, "<f8") && write_npy(d + "/keys.npy", keys.data(), nk, "<i4");
+        ok = ok && write_npy(d + "/seq_input.npy", seq_input.data(), nk, "<i4") && write_npy(d + "/rseq.npy", rseq.data(), nr, "<i4");
+        if (!ok) {
+            std::cerr << "cannot write the trace under " << d << "\n";
+            return false;
+        }
+    }
 
     if (spg) {
         std::vector<int64_t> c_ip((size_t)nrow + 1);

@@ -48,7 +48,7 @@ def test_reference_binary_output_format(tmp_path):
 def test_harness_end_to_end(tmp_path):
     cases = {"tiny": (5000,) + synth.uniform(5000, 40000, 1), "vals": (1 << 11,) + synth.rmat(11, 8, 21, True)}
     _workdir(tmp_path, cases)
-    env = dict(os.environ, SPMM_HARNESS_SPGEMM="1")
+    env = dict(os.environ, SPMM_HARNESS_SPGEMM="1", SPMM_HARNESS_TRACE=str(tmp_path / "trace"))
     r = subprocess.run([SERIAL], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert r.stdout == "----name:tiny----\n----name:vals----\n"
@@ -63,4 +63,11 @@ def test_harness_end_to_end(tmp_path):
         assert rep["nnz_c"] == int(c_ip[-1]) and rep["products"] == orc.row_products(ip, ix, ip)[1]
         assert rep["c_indices_fnv1a64"] == f"{orc.fnv(c_ix):016x}"
         assert rep["c_value_sum"] == float(c_d.sum())
-        assert rep["blocks"] == orc.trace_formats(n, ip, ix, d)["bnum"]
+        T = orc.trace_formats(n, ip, ix, d)
+        assert rep["blocks"] == T["bnum"]
+        # the on-disk trace: every array of the pipeline, equal to the oracle's (stable tie order)
+        for key, want in T.items():
+            if key == "bnum":
+                continue
+            got = np.load(tmp_path / "trace" / name / f"{key}.npy")
+            assert got.dtype == want.dtype and np.array_equal(got, want), key
