@@ -151,6 +151,14 @@ typedef struct {
 } spmm_trace;
 int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t threshold, spmm_trace* out);
 
+/* ---- y = A x read from the packed formats of spmm_trace_formats (HOST pointers; `tr` holds the outputs
+ *      of that call: seq_bitmap, r_indptr, bsize_list, bnum, panel_ptr, panel_list, spv8_list,
+ *      out_seq_all, b_indptr, b_local, b_data, keys, n_keys, seq_offset must be set).  x has ncol and y
+ *      nrow entries, both in the ORIGINAL numbering of the matrix.  No counterpart in the reference, which
+ *      produces the formats (serial_newblock_clock.cpp:336-399 interleave, :187-204 local column
+ *      numbers) and stops; this is their consumer: one wave per 8 packed rows. */
+int spmm_spv8_spmv(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x, double* y);
+
 /* ---- the stages of the pipeline one by one (HOST pointers, caller-allocated outputs).  Each
  *      call uploads its inputs, runs the stage on the GPU and downloads the outputs;
  *      spmm_last_kernel_ms() gives the kernel time of the last call.  Chaining them reproduces

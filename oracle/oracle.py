@@ -220,6 +220,43 @@ def trace_formats(ncol, indptr, indices, data, sect=2048, threshold=65536, sort_
     return out
 
 
+def spv8_spmv(T, x):
+    """y = A x read from the packed per-block formats of trace_formats() (the layout written at
+    serial_newblock_clock.cpp:336-399 and :187-204): block b holds rows bsize_list[b]..bsize_list[b+1] of the
+    reordered matrix in out_seq order; its element stream starts at r_indptr[bsize_list[b]]; b_indptr gives
+    block-local row offsets; inside panel p the first spv8_list[p] rows are groups of 8 equal-length rows stored
+    element-interleaved (element r of row c at 8*r + c); b_local are per-block column numbers whose original ids
+    are keys[seq_offset[b] + local].  Packed row t of block b is original row seq_bitmap[bs + out_seq_all[bs + t]].
+    Plain Python loops: small inputs only."""
+    x = np.asarray(x, F64)
+    nrow = T["seq_bitmap"].size
+    y = np.zeros(nrow, F64)
+    bs_list, ro = T["bsize_list"], T["r_indptr"]
+    for b in range(T["bnum"]):
+        bs, be = int(bs_list[b]), int(bs_list[b + 1])
+        base = int(ro[bs])
+        bip = T["b_indptr"][bs + b: be + b + 1]
+        pl = T["panel_list"][T["panel_ptr"][b]: T["panel_ptr"][b + 1]]
+        sp = T["spv8_list"][T["panel_ptr"][b] - b: T["panel_ptr"][b + 1] - b - 1]
+        xk = x[T["keys"][T["seq_offset"][b]: T["seq_offset"][b + 1]]]
+        grouped = np.zeros(be - bs, bool)
+        for p in range(len(pl) - 1):
+            grouped[pl[p]: pl[p] + sp[p]] = True
+        for t in range(be - bs):
+            if grouped[t]:
+                g0 = t - (t - int(pl[np.searchsorted(pl, t, side="right") - 1])) % 8
+                L = int(bip[g0 + 1] - bip[g0])
+                pos = base + int(bip[g0]) + (t - g0) + 8 * np.arange(L)
+            else:
+                pos = base + np.arange(int(bip[t]), int(bip[t + 1]))
+            orig = T["seq_bitmap"][bs + T["out_seq_all"][bs + t]]
+            acc = 0.0
+            for q in pos:
+                acc += T["b_data"][q] * xk[T["b_local"][q]]
+            y[orig] = acc
+    return y
+
+
 def spgemm_symbolic(nrow, ncolB, a_indptr, a_indices, b_indptr, b_indices):
     a_indptr, a_indices, b_indptr, b_indices = map(_i32, (a_indptr, a_indices, b_indptr, b_indices))
     c_indptr = np.empty(nrow + 1, I64)

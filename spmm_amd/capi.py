@@ -196,6 +196,24 @@ class Context:
                    keys=a["keys"][:nk].copy(), seq_input=a["seq_input"][:nk].copy())
         return out
 
+    def spv8_spmv(self, T, ncol, x):
+        """y = A x read from the packed formats in T (the dict trace_formats returns); x and y are in the
+        original numbering of the matrix."""
+        keep = {k: _np(T[k], F64 if k == "b_data" else I32) for k in
+                ("seq_bitmap", "r_indptr", "bsize_list", "seq_offset", "panel_ptr", "panel_list", "spv8_list", "out_seq_all",
+                 "b_indptr", "b_local", "b_data", "keys")}
+        o = TraceOut()
+        for k, v in keep.items():
+            setattr(o, k, v.ctypes.data)
+        o.bnum, o.n_keys = int(T["bnum"]), int(keep["keys"].size)
+        o.n_panel_entries, o.n_spv8 = int(keep["panel_list"].size), int(keep["spv8_list"].size)
+        nrow, nnz = keep["seq_bitmap"].size, keep["b_local"].size
+        x = _np(x, F64)
+        assert x.size == ncol
+        y = np.empty(nrow, F64)
+        _chk(lib().spmm_spv8_spmv(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), C.byref(o), _p(x), _p(y)))
+        return y
+
     # ---- the stages one by one (host arrays) ---------------------------------------
     def bitmap_reorder(self, A, sect=2048):
         """a3 (bitmap.h:108-170) -> (seq, Csr of the reordered matrix)."""

@@ -129,3 +129,33 @@ def test_stage_entry_points_chain_to_the_pipeline(ctx, threshold, sect):
     assert np.array_equal(seq_input, o_in) and np.array_equal(rseq, o_rseq)
     with pytest.raises(capi.SpmmError):
         ctx.wbseq(n, seq, P["out_seq_all"], bsize, np.array([n + 5], np.int32))    # a key that is no row id
+
+
+@pytest.mark.parametrize("case", ["tiny", "rmat11_small_blocks", "rmat16"])
+def test_spmv_over_the_packed_formats(ctx, case):
+    """The consumer of the 8-row interleave and the per-block column numbers: y = A x computed from the arrays
+    of trace_formats equals the CSR product, exactly for small integer x, within 1e-12 relative for random x.
+    The oracle's own walk over the packed formats is checked against the CSR product on the small cases."""
+    if case == "tiny":
+        n, thr = 5000, 65536
+        row, col = synth.uniform(n, 40000, 1)
+    elif case == "rmat11_small_blocks":
+        n, thr = 1 << 11, 300
+        row, col = synth.rmat(11, 8, 21, True)
+    else:
+        n, thr = 1 << 16, 65536
+        row, col = synth.rmat(16, 12, 5, True)
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    A = capi.Csr(n, n, ip, ix, d)
+    T = ctx.trace_formats(A, threshold=thr)
+    assert sum(T["spv8_list"]) > 0 and (case != "rmat11_small_blocks" or T["bnum"] > 10)
+    import scipy.sparse as sp
+    M = sp.csr_matrix((d, ix, ip), shape=(n, n))
+    rng = np.random.default_rng(2)
+    xi = rng.integers(1, 9, n).astype(np.float64)
+    y = ctx.spv8_spmv(T, n, xi)
+    assert np.array_equal(y, M @ xi)
+    if n <= 5000:
+        assert np.array_equal(orc.spv8_spmv(orc.trace_formats(n, ip, ix, d, threshold=thr), xi), M @ xi)
+    xr = rng.standard_normal(n)
+    np.testing.assert_allclose(ctx.spv8_spmv(T, n, xr), M @ xr, rtol=1e-12, atol=1e-12)
