@@ -65,6 +65,7 @@ struct spmm_ctx {
     bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int adaptive = 1;       // numeric k_win: window widths follow the row's product distribution
     int sym_cfg = 0;        // symbolic window kernel: 0 = k_symd (tiered sweep), 1 = k_win
+    long long light_max = -1;   // window rows with at most this many products use the small cursor workgroups (0 = none, < 0 = by the number of table windows)
     int giant_tasks = 16, giant_chunk = 1;   // workgroups per split row; consecutive table windows per turn
     int giant_len = 8192;   // dense rows with more entries of A than this are the ones that get split
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)

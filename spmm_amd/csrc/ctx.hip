@@ -43,6 +43,7 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     if (const char* e = getenv("SPMM_SYM_CFG")) c->sym_cfg = atoi(e);
     if (const char* e = getenv("SPMM_GIANT_TASKS")) c->giant_tasks = atoi(e) > 1 ? atoi(e) : 2;
     if (const char* e = getenv("SPMM_GIANT_CHUNK")) c->giant_chunk = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("SPMM_LIGHT_MAX")) c->light_max = atoll(e);
     if (const char* e = getenv("SPMM_SPLIT_GIANT")) c->split_giant = atoi(e);
     if (const char* e = getenv("SPMM_GIANT_LEN")) c->giant_len = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("SPMM_ADAPTIVE")) c->adaptive = atoi(e);

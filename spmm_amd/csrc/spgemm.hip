@@ -40,7 +40,7 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_N = 12 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_N = 12 };
 
 // ---------------------------------------------------------------------------
 // P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_e
                                                   int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
                                                   int32_t* __restrict__ list_m,
                                                   int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
-                                                  long long dense_thr, int giant_mode, int giant_len, int32_t* __restrict__ gslot,
+                                                  long long dense_thr, long long light_max, int giant_mode, int giant_len, int32_t* __restrict__ gslot,
                                                   int32_t* __restrict__ list_g, long long* __restrict__ counters) {
     int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_e
             list_w[at] = (int32_t)row;
             key_w[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);   // ascending key = descending P
             if (p >= dense_thr) atomicAdd((unsigned long long*)&counters[CNT_DENSE], 1ull);
+            else if (p <= light_max) atomicAdd((unsigned long long*)&counters[CNT_LIGHT], 1ull);
         } else if (p > ESC_S_CAP) {
             list_l[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_L], 1ull)] = (int32_t)row;
         } else if (p > 0) {
@@ -568,15 +569,18 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val,
                                                  unsigned long long* __restrict__ stamps, int dbg, int adaptive) {
     static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
-    static_assert(!NUMERIC || VALS <= WORDS, "column staging reuses the rank-prefix array");
+    // the 256-thread form serves rows of at most 65535 products: ranks fit 16 bits, and two workgroups fit a CU
+    constexpr bool PRE16 = NUMERIC && THREADS == 256;
+    using pre_t = typename std::conditional<PRE16, uint16_t, uint32_t>::type;
+    static_assert(!NUMERIC || (size_t)VALS * 4 <= (size_t)WORDS * sizeof(pre_t), "column staging reuses the rank-prefix array");
     static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
     constexpr int WPT = WORDS / THREADS;
     constexpr int NW = THREADS / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t* bits = (uint32_t*)smem;
-    uint32_t* pre = bits + WORDS;                                                       // NUMERIC
-    double* vals = (double*)(smem + (size_t)WORDS * 8);                                 // NUMERIC
-    double* dir_av = (double*)(smem + (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 : (size_t)WORDS * 4));
+    pre_t* pre = (pre_t*)(bits + WORDS);                                                // NUMERIC
+    double* vals = (double*)(smem + (size_t)WORDS * (4 + sizeof(pre_t)));               // NUMERIC
+    double* dir_av = (double*)(smem + (NUMERIC ? (size_t)WORDS * (4 + sizeof(pre_t)) + (size_t)VALS * 8 : (size_t)WORDS * 4));
     int2* dir_buf = (int2*)(dir_av + (NUMERIC ? THREADS : 0));                          // 2 x (THREADS + 1) records
     int32_t* tmp = (int32_t*)(dir_buf + 2 * (THREADS + 1));                             // 3 scan buffers of NW+1
     int32_t* tmp_dir = tmp + (NW + 1);
@@ -694,7 +698,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         if (NUMERIC && single_chunk) {
             // product -> entry map of a register-resident window: cleared here, marked after the
             // scan, both ordered by the barriers of the directory build
-            static_assert(!NUMERIC || (U == 8 && 2 * U * THREADS <= WORDS * 4), "one 16-byte store per thread clears the map");
+            static_assert(!NUMERIC || (U == 8 && 2 * U * THREADS <= WORDS * sizeof(pre_t)), "one 16-byte store per thread clears the map");
             ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
             if (tid < NW) wave_ent[tid] = 0;
         }
@@ -860,7 +864,19 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         int cntw;
         const int ex = block_exclusive_scan_1b<THREADS, int32_t>(s, tmp_pre, &cntw);
         if (!(dbg & 32)) {
-            if (fullw) {
+            if (fullw && PRE16) {
+                if constexpr (PRE16 && WPT % 8 == 0) {
+                    uint32_t r = (uint32_t)ex;
+#pragma unroll
+                    for (int j = 0; j < WPT / 8; j++) {
+                        uint32_t h[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { h[q] = r; r += __popc(myw[8 * j + q]); }
+                        ((uint4*)pre)[tid * (WPT / 8) + j] =
+                            make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                    }
+                }
+            } else if (fullw) {
                 uint32_t r = (uint32_t)ex;
 #pragma unroll
                 for (int j = 0; j < WPT / 4; j++) {
@@ -875,7 +891,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                 int r = ex;
 #pragma unroll
                 for (int j = 0; j < WPT; j++)
-                    if (j < wpt) { pre[tid * wpt + j] = (uint32_t)r; r += __popc(myw[j]); }
+                    if (j < wpt) { pre[tid * wpt + j] = (pre_t)r; r += __popc(myw[j]); }
             }
         }
         const bool staged = cntw <= VALS;
@@ -1619,7 +1635,7 @@ constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + 
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
-    return (NUMERIC ? (size_t)WORDS * 8 + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
+    return (NUMERIC ? (size_t)WORDS * (THREADS == 256 ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
            (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
            (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0);   // adaptive-window sums (at most 1024 table windows), wave bases
 }
@@ -1660,6 +1676,7 @@ struct Bins {
     int32_t *list_s, *list_l, *list_m, *list_w, *list_g;   // list_g: dense rows split into window ranges
     int32_t* gslot;      // row -> slot of its per-window counts, or -1
     uint32_t* wcnt;      // [slot][table window] entries of C, written by the symbolic kernel
+    long long n_light;   // the last n_light rows of list_w have at most light_max products
     long long n_s, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
@@ -1736,6 +1753,11 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     int32_t nr = row_end - row_beg;
     const long long dense_thr = dense_threshold(ctx, out->nbase);
+    // Window rows light enough for the 256-thread cursor workgroups (2048 products per register-resident
+    // window, 16 table windows per window at most): 128 products per table window unless set, never more
+    // than 65535 (16-bit ranks).
+    long long light_max = ctx->light_max >= 0 ? ctx->light_max : 128ll * out->nbase;
+    if (light_max > 65535) light_max = 65535;
     // the symbolic call numbers the giant rows; a numeric call on the same matrices splits them when the
     // symbolic kernel left their per-window counts
     const bool can_count = ctx->split_giant && ctx->sym_cfg == 0 && out->shift <= 20 && out->nbase >= 2 * ctx->giant_tasks * ctx->giant_chunk &&
@@ -1750,7 +1772,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, row_beg, row_end,
-                           out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, giant_mode,
+                           out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
                            ctx->giant_len, out->gslot, out->list_g, counters);
     long long* h = (long long*)ctx->pinned;
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
@@ -1768,6 +1790,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->n_m = h[CNT_ESC_M];
     out->n_w = h[CNT_WIN];
     out->n_dense = h[CNT_DENSE];
+    out->n_light = h[CNT_LIGHT];
     out->n_g = h[CNT_GIANT];
     out->products = h[CNT_PRODUCTS];
     if (giant_mode == 1) pc.n_giant = (int)h[CNT_GIANT_ALL];
@@ -1851,7 +1874,17 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
     }
     if (bins.n_w > 0) {
         int ph = phase_begin(ctx, NUMERIC ? SPMM_PH_WINDOW_NUM : SPMM_PH_WINDOW_SYM);
-        if constexpr (NUMERIC) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        if constexpr (NUMERIC) {
+            // light rows (the tail of the heaviest-first list) take 256-thread workgroups, two per CU
+            long long nl = bins.n_light < bins.n_w ? bins.n_light : bins.n_w;
+            if (bins.nbase > 1024) nl = 0;
+            Bins heavy = bins, light = bins;
+            heavy.n_w = bins.n_w - nl;
+            light.list_w = bins.list_w + heavy.n_w;
+            light.n_w = nl;
+            if (heavy.n_w > 0) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            if (light.n_w > 0) CHK((launch_win<256, 8192, 2048, 8, 4, NUMERIC>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
+        }
         else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
         phase_end(ctx, ph);
     }

@@ -15,13 +15,15 @@ pytestmark = pytest.mark.gpu
 # Kernel selections the library reads from the environment when a context is created: the default
 # plan, every window row through the dense-accumulator kernel, the dense kernel off (cursor kernel
 # with 2^15-column table windows), and the cursor kernel for the symbolic phase with fixed-width
-# numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel.
+# numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel; every window
+# row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes).
 PLANS = {
     "default": {},
     "dense_all": {"SPMM_DENSE_MIN": "1"},
     "dense_off": {"SPMM_DENSE_MIN": "0"},
     "cursor_sym_fixed_windows": {"SPMM_SYM_CFG": "1", "SPMM_ADAPTIVE": "0"},
     "split_rows": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8"},
+    "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
 }
 
 
