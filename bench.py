@@ -213,7 +213,7 @@ def main():
     ph = {name: ctx.phase_ms(pid) for name, pid in
           [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
            ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN),
-           ("dense_num", capi.PH_DENSE_NUM)]}
+           ("dense_num", capi.PH_DENSE_NUM), ("light_num", capi.PH_LIGHT_NUM)]}
     ctx.profile(False)
     stamps = None
     if os.environ.get("SPMM_WIN_STAMPS") == "1":
@@ -249,9 +249,9 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (rank 0's share) ------------------------------
-    # Numeric runs two kernels over the rows above the expand-sort-compress limit: k_dense over the
-    # rows with at least dense_min products, k_win over the rest.  The one with more time per step
-    # is reported, with the algorithmic bytes of its own rows:
+    # Numeric runs three kernels over the rows above the expand-sort-compress limit: k_dense over the
+    # rows with at least dense_min products, k_win over the rest (as 256-thread workgroups for the
+    # lightest).  The one with more time per step is reported, with the algorithmic bytes of its own rows:
     #   12 B per product (column id + value of B) + 20 B per entry of A (column id, value, two
     #   table bounds) + 12 B per row (row pointers of A and C) + 12 B per entry of C written.
     esc_s, esc_l = capi.bin_limits()
@@ -259,8 +259,10 @@ def main():
     pl = prod[r_lo:r_hi]
     lens_l = (indptr[r_lo + 1:r_hi + 1] - indptr[r_lo:r_hi]).to(torch.int64)
     rowc = c_ip[1:] - c_ip[:-1]
-    masks = {"k_dense": pl >= dense_min, "k_win<numeric>": (pl > esc_l) & (pl < dense_min)}
-    times = {"k_dense": ph["dense_num"], "k_win<numeric>": ph["window_num"]}
+    light_max = max(ctx.light_max(n), esc_l)
+    masks = {"k_dense": pl >= dense_min, "k_win<numeric>": (pl > light_max) & (pl < dense_min),
+             "k_win<numeric, 256 threads>": (pl > esc_l) & (pl <= light_max) & (pl < dense_min)}
+    times = {"k_dense": ph["dense_num"], "k_win<numeric>": ph["window_num"], "k_win<numeric, 256 threads>": ph["light_num"]}
     kname = max(times, key=lambda k: times[k][0])
     wmask = masks[kname]
     P_w, nnzA_w, rows_w, nnzC_w = int(pl[wmask].sum()), int(lens_l[wmask].sum()), int(wmask.sum()), int(rowc[wmask].sum())

@@ -79,6 +79,7 @@ enum {
     SPMM_PH_RENUMBER = 11,   /* first-touch renumbering (serial_newblock_clock.cpp:187) */
     SPMM_PH_WBSEQ = 12,      /* write-back sequence (wbsort.h) */
     SPMM_PH_DENSE_NUM = 13,         /* numeric over the product-heaviest rows (dense fp64 accumulators) */
+    SPMM_PH_LIGHT_NUM = 14,         /* numeric over the lightest window rows (256-thread cursor workgroups) */
     SPMM_PH_COUNT = 32
 };
 int spmm_ctx_profile(spmm_ctx* ctx, int enable);
@@ -92,6 +93,9 @@ void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
  * *dense_min_products intermediate products take the dense-accumulator numeric kernel (INT64_MAX
  * when that kernel is switched off).  Diagnostic, no counterpart in the reference. */
 int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shift, int32_t* nbase, int64_t* dense_min_products);
+/* Window rows of A with at most *light_max_products intermediate products take the 256-thread form of the
+ * cursor kernel (0: none).  Diagnostic, no counterpart in the reference. */
+int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* light_max_products);
 
 /* ---- MatrixMarket text: replaces the reading part of csr_matrix(),
  *      serial_newblock_clock.cpp:47-104.  spmm_mtx_header (host only, no GPU) skips the leading '%'

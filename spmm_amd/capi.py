@@ -18,6 +18,7 @@ I32, I64, F64 = np.int32, np.int64, np.float64
 
 PH_BINS, PH_WINDOW_SYM, PH_ESC_SYM, PH_WINDOW_NUM, PH_ESC_NUM, PH_SCAN, PH_CSR_BUILD = range(7)
 PH_DENSE_NUM = 13
+PH_LIGHT_NUM = 14
 
 
 def bin_limits():
@@ -138,6 +139,12 @@ class Context:
         sh, nb, dm = C.c_int32(), C.c_int32(), C.c_int64()
         _chk(lib().spmm_spgemm_plan_info(self._h, C.c_int32(int(b_ncol)), C.byref(sh), C.byref(nb), C.byref(dm)))
         return int(sh.value), int(nb.value), int(dm.value)
+
+    def light_max(self, b_ncol):
+        """Window rows with at most this many products take the 256-thread cursor workgroups."""
+        v = C.c_int64()
+        _chk(lib().spmm_spgemm_light_max(self._h, C.c_int32(int(b_ncol)), C.byref(v)))
+        return int(v.value)
 
     def last_kernel_ms(self):
         return float(lib().spmm_last_kernel_ms(self._h))

@@ -1883,7 +1883,11 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             light.list_w = bins.list_w + heavy.n_w;
             light.n_w = nl;
             if (heavy.n_w > 0) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            if (light.n_w > 0) CHK((launch_win<256, 8192, 2048, 8, 4, NUMERIC>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            if (light.n_w > 0) {
+                phase_end(ctx, ph);
+                ph = phase_begin(ctx, SPMM_PH_LIGHT_NUM);
+                CHK((launch_win<256, 8192, 2048, 8, 4, NUMERIC>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            }
         }
         else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));
         phase_end(ctx, ph);
@@ -1943,6 +1947,18 @@ extern "C" int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shi
     if (shift) *shift = sh;
     if (nbase) *nbase = nb;
     if (dense_min_products) *dense_min_products = dense_threshold(ctx, nb);
+    return SPMM_OK;
+}
+
+extern "C" int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* light_max_products) {
+    ARGCHK(ctx != nullptr && b_ncol >= 0 && light_max_products != nullptr);
+    const int sh = table_shift(b_ncol, ctx->dense_min);
+    long long nb = (((int64_t)b_ncol + (1ll << sh) - 1) >> sh);
+    if (nb < 1) nb = 1;
+    long long lm = ctx->light_max >= 0 ? ctx->light_max : 128ll * nb;
+    if (lm > 65535) lm = 65535;
+    if (nb > 1024) lm = 0;
+    *light_max_products = lm;
     return SPMM_OK;
 }
 

@@ -34,7 +34,8 @@ def main():
     c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
     c_val = torch.empty(cap, dtype=torch.float64, device=dev)
     names = [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
-             ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("dense_num", capi.PH_DENSE_NUM)]
+             ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("dense_num", capi.PH_DENSE_NUM),
+             ("light_num", capi.PH_LIGHT_NUM)]
     for lo, hi in zip(edges[:-1], edges[1:]):
         sel = torch.nonzero((prod > lo) & (prod <= hi)).flatten()
         if sel.numel() == 0:

@@ -18,12 +18,13 @@ for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         short = ("k_dense" if "k_dense<" in name else "k_win<numeric>" if "k_win<1024, 8192, 8192" in name else
+                 "k_win<numeric, 256 threads>" if "k_win<256, " in name else
                  "k_digest" if "k_digest" in name else None)
         if short:
             tot[short][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[short][r["Counter_Name"]] += 1
 kernels = {}
-for k in ("k_dense", "k_win<numeric>", "k_digest"):
+for k in ("k_dense", "k_win<numeric>", "k_win<numeric, 256 threads>", "k_digest"):
     if k not in tot:
         continue
     n = calls[k]["FETCH_SIZE"]
