@@ -124,6 +124,21 @@ int spmm_csr_from_coo(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, co
 int spmm_csr_from_coo_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
                           const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
 
+/* ---- CSR build with the loader options the reference lacks (it forces every value to 1.0, keeps
+ *      duplicates and ignores symmetry, serial_newblock_clock.cpp:84, 96-98).  val may be NULL (every
+ *      value 1.0).  SPMM_COO_SYMMETRIC mirrors every off-diagonal entry (nrow == ncol); the mirrored entries
+ *      follow all the original ones, in input order.  Without SPMM_COO_SUM_DUPLICATES a row keeps the order
+ *      of that stream (as :108-112 keeps file order); with it a row's columns ascend and entries with the
+ *      same (row, column) are added in stream order.  The output arrays hold `capacity` entries (nnz, or up
+ *      to 2*nnz with SPMM_COO_SYMMETRIC; SPMM_E_CAPACITY when too small); *nnz_out entries are written. */
+enum { SPMM_COO_SYMMETRIC = 1, SPMM_COO_SUM_DUPLICATES = 2 };
+int spmm_csr_from_coo_opts(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row, const int32_t* col,
+                           const double* val, int32_t flags, int32_t capacity, int32_t* indptr, int32_t* indices, double* data,
+                           int32_t* nnz_out);
+int spmm_csr_from_coo_opts_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row, const int32_t* col,
+                               const double* val, int32_t flags, int32_t capacity, int32_t* indptr, int32_t* indices,
+                               double* data, int32_t* nnz_out);
+
 /* ---- the format-generation pipeline: replaces gen_trace_formats(),
  *      serial_newblock_clock.cpp:221-499, and hands back EVERY array it produces (the reference
  *      drops the per-block ones, :221 by-value parameters and :363).  All arrays are HOST pointers,

@@ -98,6 +98,38 @@ def csr_from_coo(nrow, row, col):
     return indptr, indices, data
 
 
+def csr_from_coo_opts(nrow, row, col, val=None, symmetric=False, sum_duplicates=False):
+    """CSR build with loader options the reference does not have (it forces values to 1.0, keeps duplicates,
+    ignores symmetry: serial_newblock_clock.cpp:84, 96-98).  Mirrored entries follow all the original ones in
+    input order; without summing a row keeps stream order (like :108-112), with summing its columns ascend and
+    equal (row, column) entries are added one after the other in stream order."""
+    row, col = np.asarray(row, np.int64), np.asarray(col, np.int64)
+    val = np.ones(row.size, F64) if val is None else np.asarray(val, F64)
+    if symmetric:
+        off = row != col
+        row, col, val = np.concatenate([row, col[off]]), np.concatenate([col, row[off]]), np.concatenate([val, val[off]])
+    if not sum_duplicates:
+        order = np.argsort(row, kind="stable")
+        r, c, v = row[order], col[order], val[order]
+    else:
+        order = np.lexsort((col, row))          # stable: equal (row, col) stay in stream order
+        r, c, v = row[order], col[order], val[order]
+        head = np.ones(r.size, bool)
+        head[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+        starts = np.flatnonzero(head)
+        out = np.empty(starts.size, F64)
+        ends = np.append(starts[1:], r.size)
+        for k, (a, b) in enumerate(zip(starts, ends)):
+            acc = v[a]
+            for j in range(a + 1, b):
+                acc += v[j]
+            out[k] = acc
+        r, c, v = r[starts], c[starts], out
+    indptr = np.zeros(nrow + 1, I32)
+    np.add.at(indptr, r + 1, 1)
+    return np.cumsum(indptr).astype(I32), c.astype(I32), v
+
+
 def row_keys(indptr, indices, sect=2048):
     indptr, indices = _i32(indptr), _i32(indices)
     keys = np.empty(indptr.size - 1, I32)

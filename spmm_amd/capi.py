@@ -178,6 +178,21 @@ class Context:
                                          _p(indptr), _p(indices), _p(data)))
 
     # ---- format-generation pipeline (serial_newblock_clock.cpp:221-499) ---------
+    def csr_from_coo_opts(self, nrow, ncol, row, col, val=None, symmetric=False, sum_duplicates=False):
+        """CSR build with caller values, symmetric expansion and duplicate summation (options the reference's
+        loader does not have, serial_newblock_clock.cpp:84, 96-98)."""
+        row, col = _np(row, I32), _np(col, I32)
+        nnz = row.size
+        v = None if val is None else _np(val, F64)
+        cap = nnz * (2 if symmetric else 1)
+        ip, ix, d = np.empty(nrow + 1, I32), np.empty(max(cap, 1), I32), np.empty(max(cap, 1), F64)
+        n_out = C.c_int32()
+        flags = (1 if symmetric else 0) | (2 if sum_duplicates else 0)
+        _chk(lib().spmm_csr_from_coo_opts(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), _p(row), _p(col),
+                                          None if v is None else _p(v), C.c_int32(flags), C.c_int32(cap), _p(ip), _p(ix), _p(d),
+                                          C.byref(n_out)))
+        return Csr(nrow, ncol, ip, ix[:n_out.value].copy(), d[:n_out.value].copy())
+
     def trace_formats(self, A, sect=2048, threshold=65536, cap_blocks=None):
         """Returns a dict with every array the pipeline produces (names as in spmm_trace)."""
         nrow, nnz = A.nrow, A.nnz

@@ -74,6 +74,42 @@ def test_csr_build_edge_cases(ctx):
         ctx.csr_from_coo(50, 10, row, col)     # column ids out of range
 
 
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("sum_duplicates", [False, True])
+@pytest.mark.parametrize("with_values", [False, True])
+def test_csr_build_loader_options(ctx, symmetric, sum_duplicates, with_values):
+    """Caller values, symmetric expansion, duplicate summation: bit for bit the oracle's result (the order of
+    every sum is fixed), and the same matrix scipy builds from the expanded entries."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    n, m = 3000, 60000
+    row = rng.integers(0, n, m).astype(np.int32)
+    col = rng.integers(0, n, m).astype(np.int32)
+    row[:2000], col[:2000] = row[2000:4000], col[2000:4000]        # duplicates
+    row[4000:4200] = col[4000:4200]                                # diagonal entries
+    row[5000:5600], col[5000:5600] = 7, rng.integers(0, 40, 600)   # one row with many repeats
+    val = rng.standard_normal(m) if with_values else None
+    M = ctx.csr_from_coo_opts(n, n, row, col, val, symmetric, sum_duplicates)
+    ip, ix, d = orc.csr_from_coo_opts(n, row, col, val, symmetric, sum_duplicates)
+    assert np.array_equal(M.indptr, ip) and np.array_equal(M.indices, ix) and np.array_equal(M.data, d)
+    v = np.ones(m) if val is None else val
+    r2, c2, v2 = row, col, v
+    if symmetric:
+        off = row != col
+        r2, c2, v2 = np.concatenate([row, col[off]]), np.concatenate([col, row[off]]), np.concatenate([v, v[off]])
+    S = sp.coo_matrix((v2, (r2, c2)), shape=(n, n)).tocsr()
+    G = sp.csr_matrix((M.data, M.indices, M.indptr), shape=(n, n))
+    assert abs(S - G).max() <= 1e-12 * max(1.0, abs(S).max())
+    if sum_duplicates:
+        G.sort_indices()
+        assert np.array_equal(G.indices, M.indices) and G.nnz == S.nnz
+    if not (symmetric or sum_duplicates or with_values):
+        P = ctx.csr_from_coo(n, n, row, col)                       # the reference's loader rule
+        assert np.array_equal(P.indptr, M.indptr) and np.array_equal(P.indices, M.indices) and np.array_equal(P.data, M.data)
+    with pytest.raises(capi.SpmmError):
+        ctx.csr_from_coo_opts(n, n + 1, row, col, val, True, sum_duplicates)    # symmetric needs a square matrix
+
+
 @pytest.mark.parametrize("name", ["tiny", "rmat10", "rmat12d", "rmat14"])
 def test_product_matches_golden(ctx, name):
     J = golden_json("spgemm_" + name)
