@@ -114,6 +114,12 @@ int spmm_mtx_entries(spmm_ctx* ctx, const char* text, size_t bytes, size_t data_
                      int64_t nnz, int32_t* row, int32_t* col);
 int spmm_mtx_entries_dev(spmm_ctx* ctx, const char* text, size_t bytes, size_t data_offset, int32_t tokens_per_entry,
                          int64_t nnz, int32_t* row, int32_t* col);
+/* The same for files with three tokens per entry, with the third token as fp64 in val[nnz] (the reference
+ * reads it into a scratch string and drops it, :96-98): the value strtod() returns, bit for bit.  Decimals of
+ * at most 2^53 in digits and 10^±22 in scale are converted on the GPU (one exact operation), all others by
+ * strtod() on the host.  SPMM_E_ARG when a value token is not a number. */
+int spmm_mtx_entries_values(spmm_ctx* ctx, const char* text, size_t bytes, size_t data_offset, int64_t nnz, int32_t* row,
+                            int32_t* col, double* val);
 
 /* ---- CSR build: replaces the in-memory part of csr_matrix(),
  *      serial_newblock_clock.cpp:78-112 (row histogram, exclusive scan, scatter that keeps

@@ -64,7 +64,7 @@ def read_mtx(path):
     return nrow.value, ncol.value, row, col
 
 
-def mtx_tokens(text):
+def mtx_tokens(text, values=False):
     """Token-level restatement of the reader, serial_newblock_clock.cpp:47-104, on the bytes of a file:
     leading '%' lines skipped (:50, :64); `fin >> num_row >> num_col >> num_lines` (:65); two or three
     tokens per entry decided by the ' ' bytes of the line after the size line (:52-58, :80); then
@@ -85,6 +85,12 @@ def mtx_tokens(text):
         raise ValueError("fewer tokens than entries")
     row = np.array([int(t) for t in tok[0:per * nnz:per]], dtype=np.int64) - 1
     col = np.array([int(t) for t in tok[1:per * nnz:per]], dtype=np.int64) - 1
+    if values:
+        # the token the reference reads into a scratch string and drops (:96-98), as the fp64 strtod() gives
+        # (Python's float() is the same correctly rounded conversion)
+        if per != 3:
+            raise ValueError("no value tokens")
+        return nrow, ncol, row.astype(I32), col.astype(I32), np.array([float(t) for t in tok[2:3 * nnz:3]], F64)
     return nrow, ncol, row.astype(I32), col.astype(I32)
 
 

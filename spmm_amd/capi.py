@@ -160,6 +160,17 @@ class Context:
         _chk(lib().spmm_mtx_entries(self._h, buf, C.c_size_t(len(buf)), off, per, nnz, _p(row), _p(col)))
         return nrow.value, ncol.value, row, col
 
+    def mtx_parse_values(self, text):
+        """bytes of a MatrixMarket coordinate file with values -> (nrow, ncol, row, col, val)."""
+        buf = bytes(text)
+        nrow, ncol, nnz, off, per = C.c_int32(), C.c_int32(), C.c_int64(), C.c_size_t(), C.c_int32()
+        _chk(lib().spmm_mtx_header(buf, C.c_size_t(len(buf)), C.byref(nrow), C.byref(ncol), C.byref(nnz), C.byref(off), C.byref(per)))
+        if per.value != 3:
+            raise SpmmError(-1, "mtx: the entries have no value token")
+        row, col, val = np.empty(nnz.value, I32), np.empty(nnz.value, I32), np.empty(nnz.value, F64)
+        _chk(lib().spmm_mtx_entries_values(self._h, buf, C.c_size_t(len(buf)), off, nnz, _p(row), _p(col), _p(val)))
+        return nrow.value, ncol.value, row, col, val
+
     def mtx_entries_dev(self, text_ptr, nbytes, data_offset, per, nnz, row_ptr, col_ptr):
         _chk(lib().spmm_mtx_entries_dev(self._h, C.c_void_p(text_ptr), C.c_size_t(nbytes), C.c_size_t(data_offset), C.c_int32(per),
                                         C.c_int64(nnz), C.c_void_p(row_ptr), C.c_void_p(col_ptr)))

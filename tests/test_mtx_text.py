@@ -91,3 +91,44 @@ def test_gpu_reader_large_text_round_trip(values):
         ctx.close()
     ip, ix, _ = orc.csr_from_coo(n, (r - 1).astype(np.int32), (c - 1).astype(np.int32))
     assert np.array_equal(M.indptr, ip) and np.array_equal(M.indices, ix)
+
+
+TRICKY = ["0", "-0.0", "1", "-1", "3.25", "+3.25E+2", ".5", "5.", "1e22", "1e23", "1e-22", "1e-23", "9007199254740991", "9007199254740992",
+          "9007199254740993", "0.1", "0.30000000000000004", "2.2250738585072014e-308", "4.9e-324", "1e-400", "1.7976931348623157e308",
+          "1e400", "123456789012345678901234567890", "0.000000000000000000000000000001", "1.5e+300", "6.02214076e23", "inf", "-inf",
+          "12345.678901234567", "1E5", "000123.4500", "1e0000000005", "0e999", "7.", "-.25e-2"]
+
+
+def _values_text(tokens, n=97):
+    body = "".join(f"{1 + i % n} {1 + (7 * i) % n} {t}\n" for i, t in enumerate(tokens))
+    return f"%%MatrixMarket matrix coordinate real general\n{n} {n} {len(tokens)}\n{body}".encode()
+
+
+def test_oracle_reader_values():
+    nrow, ncol, row, col, val = orc.mtx_tokens(_values_text(TRICKY), values=True)
+    assert val.tolist() == [float(t) for t in TRICKY] and row[3] == 3 and col[3] == 21
+
+
+@pytest.mark.gpu
+def test_gpu_reader_values_equal_strtod():
+    """Value tokens: short decimals are converted on the GPU, the rest by strtod on the host; both must give
+    the correctly rounded fp64, bit for bit (Python's float() is the yardstick), for hand-picked edge cases and
+    for a few hundred thousand random ones in several notations."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(200000) * 10.0 ** rng.integers(-30, 30, 200000)
+    tokens = TRICKY + [repr(float(v)) for v in x[:50000]] + [f"{v:.6e}" for v in x[50000:100000]] + \
+        [f"{v:.3f}" for v in x[100000:150000] % 1000] + [str(int(v)) for v in (x[150000:] % 1e6)]
+    text = _values_text(tokens, n=100003)
+    ctx = capi.Context(0)
+    try:
+        nrow, ncol, row, col, val = ctx.mtx_parse_values(text)
+        want = np.array([float(t) for t in tokens])
+        assert np.array_equal(val.view(np.uint64), want.view(np.uint64))          # bit for bit, signed zeros included
+        o = orc.mtx_tokens(text, values=True)
+        assert np.array_equal(row, o[2]) and np.array_equal(col, o[3])
+        with pytest.raises(capi.SpmmError):
+            ctx.mtx_parse_values(_values_text(["1.5", "abc", "2"]))
+        with pytest.raises(capi.SpmmError):
+            ctx.mtx_parse_values(_values_text(["1.5", "1.5x", "2"]))
+    finally:
+        ctx.close()
