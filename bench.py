@@ -290,6 +290,21 @@ def main():
                     numeric_gflops=round(2.0 * P_w / (t_w_ms * 1e-3) / 1e9, 1) if t_w_ms > 0 else None,
                     table=dict(shift=shift, windows=nbase, dense_min_products=dense_min))
 
+    # ---- the two phases as wholes (rank 0's rows), against the same 8 TB/s --------------------------
+    # symbolic: 4 B per product (column id of B) + 12 B per entry of A + row pointers + 8 B per row count;
+    # numeric: 12 B per product + 20 B per entry of A + row pointers of A and C + 12 B per entry of C.
+    nnzA_l, nnzC_l = int(lens_l.sum()), int(rowc.sum())
+    t_num = sum(ph[k][0] for k in ("dense_num", "window_num", "light_num", "esc_num")) / args.steps
+    t_sym = sum(ph[k][0] for k in ("window_sym", "esc_sym", "scan")) / args.steps
+    b_num = 12 * P_local + 20 * nnzA_l + 12 * (rows_l + 1) + 12 * nnzC_l
+    b_sym = 4 * P_local + 12 * nnzA_l + 4 * (rows_l + 1) + 8 * rows_l
+    phase_totals = {
+        "numeric": dict(ms_per_step=round(t_num, 3), gflops=round(2.0 * P_local / (t_num * 1e-3) / 1e9, 1) if t_num > 0 else None,
+                        algorithmic_bytes=b_num, frac_of_hbm_peak=round(b_num / (t_num * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t_num > 0 else None),
+        "symbolic": dict(ms_per_step=round(t_sym, 3), algorithmic_bytes=b_sym,
+                         frac_of_hbm_peak=round(b_sym / (t_sym * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t_sym > 0 else None),
+        "bins_ms_per_step": round(ph["bins"][0] / args.steps, 3)}
+
     # ---- CPU baseline: the oracle's serial Gustavson on the first rows of the same matrix -----
     cpu = None
     if not args.no_cpu and world == 1:
@@ -325,7 +340,7 @@ def main():
                            step="symbolic+numeric", c_row_blocks_per_step=state["blocks"], rank0_rows=rows_l,
                            b_allgather_ms=round(b_allgather_ms, 3), setup_s=round(setup_s, 1)),
                phases_ms_per_step={k: round(v[0] / args.steps, 3) for k, v in ph.items()},
-               roofline=roofline, cpu_baseline=cpu)
+               phase_totals_rank0=phase_totals, roofline=roofline, cpu_baseline=cpu)
     if stamps:
         out["stamps"] = stamps
     print(json.dumps(out), flush=True)
