@@ -104,16 +104,27 @@ __global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol
     }
 }
 
-// Bin rows [row_beg,row_end) by P_i.
-__global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_end, const int64_t* __restrict__ prod,
-                                                  const int32_t* __restrict__ a_ip,
-                                                  int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
-                                                  int32_t* __restrict__ list_m,
-                                                  int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
-                                                  long long dense_thr, long long light_max, int giant_mode, int giant_len, int32_t* __restrict__ gslot,
-                                                  int32_t* __restrict__ list_g, long long* __restrict__ counters) {
-    int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Bin rows [row_beg,row_end) by P_i.  List positions are handed out per workgroup: the waves count their
+// rows of every class by ballot, one thread per class adds the workgroup's total to the global counter, and
+// a row's position is the workgroup's base + the count of the waves before its own + its rank in the wave.
+constexpr int CLS_THREADS = 1024;
+__global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32_t row_end, const int64_t* __restrict__ prod,
+                                                          const int32_t* __restrict__ a_ip,
+                                                          int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
+                                                          int32_t* __restrict__ list_m,
+                                                          int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
+                                                          long long dense_thr, long long light_max, int giant_mode, int giant_len,
+                                                          int32_t* __restrict__ gslot, int32_t* __restrict__ list_g,
+                                                          long long* __restrict__ counters) {
+    constexpr int NW = CLS_THREADS / 64;
+    enum { C_NONE = 0, C_G = 1, C_M = 2, C_W = 3, C_L = 4, C_S = 5, C_DENSE = 6, C_LIGHT = 7, C_N = 8 };
+    __shared__ int32_t wcnt[NW][C_N];
+    __shared__ long long gbase[C_N];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
+    int cat = C_NONE;
+    bool dense = false, light = false;
     if (row < row_end) {
         p = prod[row];
         const int len_a = a_ip[row + 1] - a_ip[row];
@@ -125,24 +136,51 @@ __global__ void __launch_bounds__(256) k_classify(int32_t row_beg, int32_t row_e
         const bool is_win = p > ESC_R_CAP || (p > ESC_S_CAP && many_entries);   // the row takes the window kernels
         if (giant_mode == 1 && is_win && p >= dense_thr && len_a > giant_len)
             gslot[row] = (int)atomicAdd((unsigned long long*)&counters[CNT_GIANT_ALL], 1ull);
-        if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) {
-            list_g[(int)atomicAdd((unsigned long long*)&counters[CNT_GIANT], 1ull)] = (int32_t)row;
-        } else if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) {
-            list_m[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_M], 1ull)] = (int32_t)row;
-        } else if (p > ESC_L_CAP || (p > ESC_S_CAP && many_entries)) {
-            int at = (int)atomicAdd((unsigned long long*)&counters[CNT_WIN], 1ull);
+        if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) cat = C_G;
+        else if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) cat = C_M;
+        else if (is_win) {
+            cat = C_W;
+            dense = p >= dense_thr;
+            light = !dense && p <= light_max;
+        } else if (p > ESC_S_CAP) cat = C_L;
+        else if (p > 0) cat = C_S;
+    }
+    // per wave: rows of every class, and this row's rank among those of its class
+    int rank = 0;
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int c = C_G; c <= C_S; c++) {
+        const unsigned long long m = __ballot(cat == c);
+        if (cat == c) rank = __popcll(m & lt);
+        if (lane == 0) wcnt[wv][c] = __popcll(m);
+    }
+    {
+        const unsigned long long md = __ballot(dense), ml = __ballot(light);
+        if (lane == 0) { wcnt[wv][C_DENSE] = __popcll(md); wcnt[wv][C_LIGHT] = __popcll(ml); }
+    }
+    __syncthreads();
+    if (threadIdx.x >= C_G && threadIdx.x < C_N) {
+        const int c = threadIdx.x;
+        const int slot = c == C_G ? CNT_GIANT : c == C_M ? CNT_ESC_M : c == C_W ? CNT_WIN : c == C_L ? CNT_ESC_L :
+                         c == C_S ? CNT_ESC_S : c == C_DENSE ? CNT_DENSE : CNT_LIGHT;
+        int run = 0;
+        for (int w = 0; w < NW; w++) { const int x = wcnt[w][c]; wcnt[w][c] = run; run += x; }
+        gbase[c] = run ? (long long)atomicAdd((unsigned long long*)&counters[slot], (unsigned long long)run) : 0ll;
+    }
+    __syncthreads();
+    if (cat != C_NONE) {
+        const int at = (int)gbase[cat] + wcnt[wv][cat] + rank;
+        if (cat == C_G) list_g[at] = (int32_t)row;
+        else if (cat == C_M) list_m[at] = (int32_t)row;
+        else if (cat == C_L) list_l[at] = (int32_t)row;
+        else if (cat == C_S) list_s[at] = (int32_t)row;
+        else {
             list_w[at] = (int32_t)row;
             key_w[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);   // ascending key = descending P
-            if (p >= dense_thr) atomicAdd((unsigned long long*)&counters[CNT_DENSE], 1ull);
-            else if (p <= light_max) atomicAdd((unsigned long long*)&counters[CNT_LIGHT], 1ull);
-        } else if (p > ESC_S_CAP) {
-            list_l[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_L], 1ull)] = (int32_t)row;
-        } else if (p > 0) {
-            list_s[(int)atomicAdd((unsigned long long*)&counters[CNT_ESC_S], 1ull)] = (int32_t)row;
         }
     }
     long long s = wave_reduce_sum(p);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)&counters[CNT_PRODUCTS], (unsigned long long)s);
+    if (lane == 0 && s) atomicAdd((unsigned long long*)&counters[CNT_PRODUCTS], (unsigned long long)s);
 }
 
 // ---------------------------------------------------------------------------
@@ -1771,7 +1809,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         HIPCHK(hipMemsetAsync(out->gslot, 0xff, sizeof(int32_t) * ((size_t)nrow + 1), ctx->stream));
     }
     if (nr > 0)
-        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, row_beg, row_end,
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
                            out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
                            ctx->giant_len, out->gslot, out->list_g, counters);
     long long* h = (long long*)ctx->pinned;
