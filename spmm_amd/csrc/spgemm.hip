@@ -73,8 +73,24 @@ __global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrow
             const int src = __ffsll(lm) - 1;
             lm &= lm - 1;
             const int b0 = __builtin_amdgcn_readlane(a0, src), b1 = __builtin_amdgcn_readlane(a1, src);
+            // the hub rows sit next to each other at the low row ids, so a few waves get all of them: eight
+            // independent load chains per lane keep their serial walk short
             long long t = 0;
-            for (int p = b0 + lane; p < b1; p += 64) {
+            int p = b0 + lane;
+            for (; p + 7 * 64 < b1; p += 8 * 64) {
+                int k[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) k[q] = a_ix[p + 64 * q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const bool ok = (uint32_t)k[q] < (uint32_t)nrowB;
+                    bad |= !ok;
+                    const int kk = ok ? k[q] : 0;
+                    const int d = b_ip[kk + 1] - b_ip[kk];
+                    t += ok ? d : 0;
+                }
+            }
+            for (; p < b1; p += 64) {
                 const int k = a_ix[p];
                 if ((uint32_t)k >= (uint32_t)nrowB) { bad = true; continue; }
                 t += b_ip[k + 1] - b_ip[k];
