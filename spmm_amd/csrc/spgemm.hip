@@ -311,6 +311,29 @@ __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ li
     const int row = list[blockIdx.x];
     const int a0 = a_ip[row], lenA = a_ip[row + 1] - a0;
 
+    // A row with one entry is that row of B times a number: ascending columns already, and distinct ones
+    // unless the row of B repeats a column (rows of B may: the loader keeps duplicates).
+    if (lenA == 1) {
+        const int k = a_ix[a0];
+        const int b0 = b_ip[k], len = b_ip[k + 1] - b0;
+        int dup = 0;
+        for (int i = tid + 1; i < len; i += THREADS) dup |= b_ix[b0 + i] == b_ix[b0 + i - 1];
+        dup = __syncthreads_or(dup);
+        if (dup) goto general;
+        if (NUMERIC) {
+            const double a = a_val[a0];
+            const int64_t obase = c_ip[row] - c_ip[row_beg];
+            for (int i = tid; i < len; i += THREADS) {
+                c_ix[obase + i] = b_ix[b0 + i];
+                c_val[obase + i] = a * b_val[b0 + i];
+            }
+        } else if (tid == 0) {
+            rowcnt[row] = len;
+        }
+        return;
+    }
+general:
+
     // ---- expand ------------------------------------------------------------------
     int run = 0;
     for (int e0 = 0; e0 < lenA; e0 += THREADS) {
