@@ -379,7 +379,52 @@ general:
     uint16_t* id = idx_b;
     uint16_t* mycnt = cnt + wv * 256;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (int shift = 0; shift < key_bits; shift += 8) {
+    // Rows with at most four entries (most of the rows sorted here) are at most four ascending lists laid end
+    // to end: the place of a product in the merged order is its index in its own list plus, for every other
+    // list, the number of elements that go before it there (those not above it in an earlier list, those below
+    // it in a later one), i.e. up to three binary searches in LDS instead of three radix passes.
+    bool merged = false;
+    if (lenA <= 4) {
+        int o[5];
+        o[0] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int len = 0;
+            if (e < lenA) {
+                const int k = a_ix[a0 + e];
+                len = b_ip[k + 1] - b_ip[k];
+            }
+            o[e + 1] = o[e] + len;
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int p = j * THREADS + tid;
+            if (p < N) {
+                const uint32_t x = key_a[p];
+                const int l = (p >= o[1]) + (p >= o[2]) + (p >= o[3]);
+                int pos = p - (l == 0 ? o[0] : l == 1 ? o[1] : l == 2 ? o[2] : o[3]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q == l || q >= lenA) continue;
+                    int lo = o[q], hi = o[q + 1];
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const uint32_t y = key_a[mid];
+                        if (q < l ? y <= x : y < x) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    pos += lo - o[q];
+                }
+                key_b[pos] = x;
+                if (NUMERIC) idx_b[pos] = (uint16_t)p;
+            }
+        }
+        __syncthreads();
+        ks = key_b;
+        is = idx_b;
+        merged = true;
+    }
+    for (int shift = 0; shift < (merged ? 0 : key_bits); shift += 8) {
         ((uint64_t*)mycnt)[lane] = 0ull;          // 256 counters of 16 bits per wave
         wave_sync_lds();
         uint32_t k[EPT];
