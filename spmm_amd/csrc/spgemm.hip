@@ -283,6 +283,9 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
 // workgroup: one scan over [digit][wave]); equal columns end adjacent.  Values are not carried
 // through the sort: the compress step reads a*b through the sorted index (position in B and entry
 // of A per product).
+#ifndef ESC_MERGE_MAX
+#define ESC_MERGE_MAX 4
+#endif
 template <int THREADS, int CAP, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                   const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
@@ -379,16 +382,16 @@ general:
     uint16_t* id = idx_b;
     uint16_t* mycnt = cnt + wv * 256;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // Rows with at most four entries (most of the rows sorted here) are at most four ascending lists laid end
+    // Rows with at most ESC_MERGE_MAX entries (most of the rows sorted here) are that many ascending lists laid end
     // to end: the place of a product in the merged order is its index in its own list plus, for every other
     // list, the number of elements that go before it there (those not above it in an earlier list, those below
     // it in a later one), i.e. up to three binary searches in LDS instead of three radix passes.
     bool merged = false;
-    if (lenA <= 4) {
-        int o[5];
+    if (lenA <= ESC_MERGE_MAX) {
+        int o[ESC_MERGE_MAX + 1];
         o[0] = 0;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < ESC_MERGE_MAX; e++) {
             int len = 0;
             if (e < lenA) {
                 const int k = a_ix[a0 + e];
@@ -401,10 +404,13 @@ general:
             const int p = j * THREADS + tid;
             if (p < N) {
                 const uint32_t x = key_a[p];
-                const int l = (p >= o[1]) + (p >= o[2]) + (p >= o[3]);
-                int pos = p - (l == 0 ? o[0] : l == 1 ? o[1] : l == 2 ? o[2] : o[3]);
+                int l = 0, ol = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 1; q < ESC_MERGE_MAX; q++)
+                    if (p >= o[q]) { l = q; ol = o[q]; }
+                int pos = p - ol;
+#pragma unroll
+                for (int q = 0; q < ESC_MERGE_MAX; q++) {
                     if (q == l || q >= lenA) continue;
                     int lo = o[q], hi = o[q + 1];
                     while (lo < hi) {
