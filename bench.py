@@ -150,7 +150,8 @@ def main():
     cum = torch.cumsum(prod, 0)
     _, esc_max = capi.bin_limits()
     _, _, dense_min_products = ctx.plan_info(n)
-    bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min_products)
+    bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min_products, max(ctx.light_max(n), esc_max),
+                                        indptr[1:] - indptr[:-1])
     r_lo, r_hi = bounds[rank], bounds[rank + 1]
     rows_l = r_hi - r_lo
     P_local = int(prod[r_lo:r_hi].sum())

@@ -59,28 +59,46 @@ def product_balanced_bounds(prod, world):
     return bounds
 
 
-# Cost model of a row shard, fitted to the measured times (symbolic + numeric) of the shards of 4- and
-# 8-rank partitions of R-MAT scale 22 on one MI355X (tools/shard_balance.py; fit within 5 %): ns per
-# intermediate product by the kernel class of its row, plus a cost per row (one workgroup each, whatever
-# the class).  The sorted rows are an order of magnitude dearer per product than the window rows.
-# Only the ratios matter.
-COST_NS = {"dense": 0.0096, "window": 0.0073, "sorted": 0.102}
-ROW_NS = 10.2
+# Cost model of a row shard, in ns per intermediate product and ns per row by the kernel class of the row, fitted
+# to the times (symbolic + numeric, one MI355X, R-MAT scale 22) of the rows of every range of products taken as a
+# matrix of their own (tools/class_cost.py).  The sorted rows are dear per product, the cursor rows per row (a row
+# pays for its column windows whatever its products).  A dense row pays per entry of its row of A as well (the
+# bounds of the window table it reads for the entry): 8.9 ns per entry next to 3.2 ps per product when the row
+# lengths are given (fitted at scales 21 and 22: balance over 8 shards 0.978 and 0.964; scale 20: 0.85); 8.2 ps
+# per product stands for both when they are not.  Only the ratios matter.
+COST_NS = {"dense": 0.0082, "window": 0.0075, "light": 0.0072, "sorted": 0.0272}
+ROW_NS = {"dense": 0.0, "window": 175.0, "light": 212.0, "sorted": 3.2}
+DENSE_WITH_LENS_NS = 0.0032
+DENSE_ENTRY_NS = 8.9
 
 
-def cost_balanced_bounds(prod, world, sorted_max, dense_min):
-    """Row boundaries like product_balanced_bounds, with every row's products weighted by the cost
-    of its kernel class (rows with at most sorted_max products are sorted, rows with at least
-    dense_min use dense accumulators) plus a fixed cost per non-empty row, so that the ranks finish
-    together and not merely hold the same number of products."""
+def row_costs(prod, sorted_max, dense_min, light_max=None, lens=None):
+    """Modelled cost (ns) of every row: rows with at most sorted_max products are sorted, rows with at least
+    dense_min use dense accumulators, the rows between are cursor rows (the small workgroups up to light_max).
+    lens: entries per row of A (optional)."""
+    p = prod.to(torch.float64)
+    w = torch.full_like(p, COST_NS["window"])
+    r = torch.full_like(p, ROW_NS["window"])
+    if light_max is not None:
+        m = prod <= light_max
+        w[m], r[m] = COST_NS["light"], ROW_NS["light"]
+    m = prod <= sorted_max
+    w[m], r[m] = COST_NS["sorted"], ROW_NS["sorted"]
+    m = prod >= dense_min
+    w[m], r[m] = COST_NS["dense"], ROW_NS["dense"]
+    if lens is not None:
+        w[m] = DENSE_WITH_LENS_NS
+        r[m] = lens.to(torch.float64)[m] * DENSE_ENTRY_NS
+    return p * w + r * (prod > 0).to(torch.float64)
+
+
+def cost_balanced_bounds(prod, world, sorted_max, dense_min, light_max=None, lens=None):
+    """Row boundaries like product_balanced_bounds, with every row weighted by the modelled cost of its kernel
+    class (row_costs), so that the ranks finish together and not merely hold the same number of products."""
     n = prod.numel()
     if n == 0:
         return [0] * (world + 1)
-    p = prod.to(torch.float64)
-    w = torch.full_like(p, COST_NS["window"])
-    w[prod <= sorted_max] = COST_NS["sorted"]
-    w[prod >= dense_min] = COST_NS["dense"]
-    cum = torch.cumsum(p * w + ROW_NS * (prod > 0).to(torch.float64), 0)
+    cum = torch.cumsum(row_costs(prod, sorted_max, dense_min, light_max, lens), 0)
     total = float(cum[-1])
     bounds = [0]
     for r in range(1, world):

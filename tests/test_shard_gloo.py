@@ -91,9 +91,14 @@ def test_cost_balanced_bounds():
     for world in (1, 2, 4, 8):
         b = shard.cost_balanced_bounds(prod, world, 8192, 262144)
         assert b[0] == 0 and b[-1] == prod.numel() and all(x <= y for x, y in zip(b, b[1:]))
-        p = prod.double()
-        w = torch.where(prod <= 8192, shard.COST_NS["sorted"], torch.where(prod >= 262144, shard.COST_NS["dense"], shard.COST_NS["window"]))
-        c = p * w + shard.ROW_NS * (prod > 0).double()
+        c = shard.row_costs(prod, 8192, 262144)
         cost = [float(c[b[r]:b[r + 1]].sum()) for r in range(world)]
         assert max(cost) - min(cost) <= 2 * float(c.max())          # balanced up to a row or two
     assert shard.cost_balanced_bounds(torch.zeros(0, dtype=torch.int64), 3, 8192, 262144) == [0, 0, 0, 0]
+    # with row lengths, a dense row of many entries weighs more than one of the same products and few entries
+    lens = torch.tensor([4000, 40, 8, 8, 8, 8, 2, 2, 2, 2] * 50, dtype=torch.int32)
+    c = shard.row_costs(prod, 8192, 262144, 65535, lens)
+    assert float(c[0]) > float(c[1]) and float(c[2]) == float(shard.row_costs(prod, 8192, 262144, 65535)[2])
+    b = shard.cost_balanced_bounds(prod, 4, 8192, 262144, 65535, lens)
+    cost = [float(c[b[r]:b[r + 1]].sum()) for r in range(4)]
+    assert max(cost) - min(cost) <= 2 * float(c.max())

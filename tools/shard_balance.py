@@ -32,7 +32,8 @@ def main():
     P_total = ctx.row_products_dev(vB, vB, prod)
     _, esc_max = capi.bin_limits()
     _, _, dense_min = ctx.plan_info(n)
-    bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min)
+    bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min, max(ctx.light_max(n), esc_max),
+                                        indptr[1:] - indptr[:-1])
     cap = int(48 * (1 << 30) / 12)
     c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
     c_val = torch.empty(cap, dtype=torch.float64, device=dev)
