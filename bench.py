@@ -334,7 +334,7 @@ def main():
             cpu["gpu_rows_match_oracle"] = True
 
     out = dict(metric="spgemm_gflops", value=round(gflops, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",
+               warmup=max(args.warmup, 1), ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=workload,
                            rows=n, nnz=nnz, products=P_total, nnz_c=nnz_c_total, partition="rows of A by product count weighted by kernel class",
