@@ -47,6 +47,30 @@ def rmat(scale, edge_factor, seed, diagonal=False, a=0.57, b=0.19, c=0.19):
     return _finish(row, col, n)
 
 
+def web_like(n=916428, m=5105039, seed=3):
+    """A graph of the size and rough shape of SNAP web-Google (916 428 pages, 5.1 M links; the file itself is not
+    available offline): geometric out-degrees scaled to m links, three targets in ten drawn from a Pareto-ranked
+    popular head, the others uniform."""
+    rng = np.random.default_rng(seed)
+    deg = rng.geometric(0.18, n)
+    deg = (deg * (m / deg.sum())).astype(np.int64) + 1
+    row = np.repeat(np.arange(n), deg)[:m]
+    pop = (rng.pareto(1.2, row.size) * 50).astype(np.int64) % n
+    col = np.where(rng.random(row.size) < 0.3, pop, rng.integers(0, n, row.size))
+    return _finish(row, col, n)
+
+
+def askubuntu_like(n=159316, m=964437, seed=5):
+    """A graph of the size and rough shape of SNAP sx-askubuntu (159 316 users, 964 437 timed interactions, about
+    0.6 M distinct pairs): both ends of an interaction drawn from heavy-tailed activity ranks (user id = n*u^3 for the
+    one who writes, n*u^4 for the one written to: a few users answer or are answered thousands of times), repeated
+    pairs collapse as in the static graph."""
+    rng = np.random.default_rng(seed)
+    src = (n * rng.random(m) ** 3).astype(np.int64)
+    dst = (n * rng.random(m) ** 4).astype(np.int64)
+    return _finish(src, dst, n)
+
+
 def write_mtx(path, n, row, col, pattern=True):
     """MatrixMarket coordinate file, 1-based, in the given entry order."""
     with open(path, "w") as f:

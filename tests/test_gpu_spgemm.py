@@ -124,6 +124,34 @@ def test_product_matches_golden(ctx, name):
     assert cd.sum() == J["products"]
 
 
+_SNAP_LIKE = {}
+
+
+def _snap_like(name):
+    """(A, c_indptr, c_indices, c_data) of the oracle for a graph of the size and rough shape of a SNAP input the
+    benchmark names (the files are not available offline); computed once for all plans."""
+    if name not in _SNAP_LIKE:
+        n, gen = {"web-Google": (916428, synth.web_like), "sx-askubuntu": (159316, synth.askubuntu_like)}[name]
+        row, col = gen()
+        ip, ix, d = orc.csr_from_coo(n, row, col)
+        o_ip = orc.spgemm_symbolic(n, n, ip, ix, ip, ix)
+        oi, od, _ = orc.spgemm_numeric(n, (ip, ix, d), (ip, ix, d), o_ip)
+        _SNAP_LIKE[name] = (capi.Csr(n, n, ip, ix, d), o_ip, oi, od)
+    return _SNAP_LIKE[name]
+
+
+@pytest.mark.parametrize("name", ["web-Google", "sx-askubuntu"])
+def test_product_snap_sized_graphs(ctx, name):
+    """Whole C of a web-Google-sized graph (5.1 M entries, every row in the smallest sorted bin) and of an
+    sx-askubuntu-sized one (0.9 M entries, 5.4e8 products, skewed rows in every bin) against the oracle."""
+    A, o_ip, oi, od = _snap_like(name)
+    c_ip, nnz_c, _ = ctx.spgemm_symbolic(A)
+    assert nnz_c == int(o_ip[-1]) and np.array_equal(c_ip, o_ip)
+    ci, cd = ctx.spgemm_numeric(A, None, c_ip)
+    assert np.array_equal(ci, oi)
+    assert np.array_equal(cd, od)
+
+
 def test_product_full_arrays_and_row_ranges(ctx):
     Z = golden_npz("spgemm_rmat10")
     A = _ones_csr(1024, Z["row"], Z["col"])
