@@ -5,6 +5,8 @@
 //
 // Rows are binned by their number of intermediate products P_i = sum_k len_B(k):
 //   P_i == 0                 nothing to do
+//   P_i <= ESC_T_CAP (128)   k_esc4: the same expand / bitonic sort / sum in a quarter of a wave, so a
+//                            64-lane workgroup has the gather chains of four rows in flight
 //   P_i <= ESC_S_CAP (512)   k_esc: one 64-lane workgroup expands the products into LDS, bitonic
 //                            sort by column, runs of equal columns summed
 //   P_i <= ESC_R_CAP (8192)  k_escr: expand (column, index) pairs, stable LSD radix sort in LDS,
@@ -25,6 +27,9 @@
 namespace {
 
 constexpr int ESC_S_CAP = 512;
+#ifndef ESC_T_CAP
+#define ESC_T_CAP 128      // rows of at most this many products go four to a wave
+#endif
 constexpr int ESC_L_CAP = 4096;
 constexpr int ESC_R_CAP = 8192;         // radix expand-sort-compress: rows with up to this many products and 65535 entries
 constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14 .. 2^17 columns
@@ -40,7 +45,7 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_N = 12 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_N = 12 };
 
 // ---------------------------------------------------------------------------
 // P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
@@ -126,14 +131,14 @@ __global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol
 constexpr int CLS_THREADS = 1024;
 __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32_t row_end, const int64_t* __restrict__ prod,
                                                           const int32_t* __restrict__ a_ip,
-                                                          int32_t* __restrict__ list_s, int32_t* __restrict__ list_l,
-                                                          int32_t* __restrict__ list_m,
+                                                          int32_t* __restrict__ list_s, int32_t s_top,
+                                                          int32_t* __restrict__ list_l, int32_t* __restrict__ list_m,
                                                           int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
                                                           long long dense_thr, long long light_max, int giant_mode, int giant_len,
                                                           int32_t* __restrict__ gslot, int32_t* __restrict__ list_g,
                                                           long long* __restrict__ counters) {
     constexpr int NW = CLS_THREADS / 64;
-    enum { C_NONE = 0, C_G = 1, C_M = 2, C_W = 3, C_L = 4, C_S = 5, C_DENSE = 6, C_LIGHT = 7, C_N = 8 };
+    enum { C_NONE = 0, C_G = 1, C_M = 2, C_W = 3, C_L = 4, C_S = 5, C_T = 6, C_DENSE = 7, C_LIGHT = 8, C_N = 9 };
     __shared__ int32_t wcnt[NW][C_N];
     __shared__ long long gbase[C_N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -159,13 +164,14 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
             dense = p >= dense_thr;
             light = !dense && p <= light_max;
         } else if (p > ESC_S_CAP) cat = C_L;
-        else if (p > 0) cat = C_S;
+        else if (p > ESC_T_CAP) cat = C_S;
+        else if (p > 0) cat = C_T;
     }
     // per wave: rows of every class, and this row's rank among those of its class
     int rank = 0;
     const unsigned long long lt = lanemask_lt();
 #pragma unroll
-    for (int c = C_G; c <= C_S; c++) {
+    for (int c = C_G; c <= C_T; c++) {
         const unsigned long long m = __ballot(cat == c);
         if (cat == c) rank = __popcll(m & lt);
         if (lane == 0) wcnt[wv][c] = __popcll(m);
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
     if (threadIdx.x >= C_G && threadIdx.x < C_N) {
         const int c = threadIdx.x;
         const int slot = c == C_G ? CNT_GIANT : c == C_M ? CNT_ESC_M : c == C_W ? CNT_WIN : c == C_L ? CNT_ESC_L :
-                         c == C_S ? CNT_ESC_S : c == C_DENSE ? CNT_DENSE : CNT_LIGHT;
+                         c == C_S ? CNT_ESC_S : c == C_T ? CNT_ESC_T : c == C_DENSE ? CNT_DENSE : CNT_LIGHT;
         int run = 0;
         for (int w = 0; w < NW; w++) { const int x = wcnt[w][c]; wcnt[w][c] = run; run += x; }
         gbase[c] = run ? (long long)atomicAdd((unsigned long long*)&counters[slot], (unsigned long long)run) : 0ll;
@@ -189,7 +195,8 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
         if (cat == C_G) list_g[at] = (int32_t)row;
         else if (cat == C_M) list_m[at] = (int32_t)row;
         else if (cat == C_L) list_l[at] = (int32_t)row;
-        else if (cat == C_S) list_s[at] = (int32_t)row;
+        else if (cat == C_T) list_s[at] = (int32_t)row;             // the tiny rows fill the list from the front,
+        else if (cat == C_S) list_s[s_top - at] = (int32_t)row;     // the other rows of the smallest bin from the back
         else {
             list_w[at] = (int32_t)row;
             key_w[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);   // ascending key = descending P
@@ -200,20 +207,19 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
 }
 
 // ---------------------------------------------------------------------------
-// Expand / sort / compress in LDS, one row per workgroup.
+// Expand / sort / compress in LDS, one row by the whole workgroup.
 template <int THREADS, int CAP, bool NUMERIC>
-__global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
-                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                                 const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
-                                                 const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
-                                                 const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
-    __shared__ int32_t skey[CAP];
-    __shared__ double sval[NUMERIC ? CAP : 1];
-    __shared__ int32_t tmp[THREADS / 64 + 1];
+__device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sval, int32_t* tmp,
+                                        const int32_t* __restrict__ a_ip,
+                                        const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                        const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                        const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                        const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                        int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
     const int tid = threadIdx.x;
-    const int row = list[blockIdx.x];
     const int a0 = a_ip[row], a1 = a_ip[row + 1];
+    int64_t obase = 0;
+    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
 
     int run = 0;
     for (int e0 = a0; e0 < a1; e0 += THREADS) {
@@ -255,8 +261,6 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
         }
     }
 
-    int64_t obase = 0;
-    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
     int outrun = 0;
     for (int c0 = 0; c0 < n2; c0 += THREADS) {
         int t = c0 + tid;
@@ -273,6 +277,137 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
         outrun += tot;
     }
     if (!NUMERIC && tid == 0) rowcnt[row] = outrun;
+}
+
+template <int THREADS, int CAP, bool NUMERIC>
+__global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                 const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                                 const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                                 const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    __shared__ int32_t skey[CAP];
+    __shared__ double sval[NUMERIC ? CAP : 1];
+    __shared__ int32_t tmp[THREADS / 64 + 1];
+    esc_row<THREADS, CAP, NUMERIC>(list[blockIdx.x], skey, sval, tmp, a_ip, a_ix, a_val, b_ip, b_ix, b_val, rowcnt, c_ip, row_beg,
+                                   c_ix, c_val);
+}
+
+// The tiny rows of the smallest bin, four per 64-lane workgroup.  Such a row is a chain of five dependent gathers of a few
+// dozen bytes each (list, row pointers of A, entries of A, row pointers of B, entries of B): latency, not
+// bandwidth, is its cost, so a row of at most CAP/4 products is expanded, sorted and compressed by 16 lanes in
+// a quarter of the LDS arrays and the wave keeps the chains of four rows in flight.
+template <int CAP, bool NUMERIC>
+__global__ void __launch_bounds__(64) k_esc4(const int32_t* __restrict__ list, const int n_list, const int32_t* __restrict__ a_ip,
+                                             const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                             const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                             const double* __restrict__ b_val, int32_t* __restrict__ rowcnt, const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                             int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    constexpr int QC = CAP / 4;
+    __shared__ int32_t skey[CAP];
+    __shared__ double sval[NUMERIC ? CAP : 1];
+    __shared__ int32_t eoff[4][16], eb0[4][16];
+    __shared__ double eav[NUMERIC ? 4 : 1][16];
+    const int lane = threadIdx.x, q = lane >> 4, ql = lane & 15;
+    const int idx = blockIdx.x * 4 + q;
+    const bool small = idx < n_list;
+    const int row = small ? list[idx] : 0;
+    int a0 = 0, a1 = 0;
+    int64_t obase = 0;
+    if (small) {
+        a0 = a_ip[row];
+        a1 = a_ip[row + 1];
+        if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
+    }
+    int32_t* qkey = skey + q * QC;
+    double* qval = sval + (NUMERIC ? q * QC : 0);
+    // expand: the 16 lanes of a quarter have the same trip count, and the shuffles stay inside the quarter
+    int run = 0;
+    for (int e0 = a0; e0 < a1; e0 += 16) {
+        const int p = e0 + ql;
+        int len = 0, b0 = 0;
+        double av = 0.0;
+        if (p < a1) {
+            const int k = a_ix[p];
+            b0 = b_ip[k];
+            len = b_ip[k + 1] - b0;
+            if (NUMERIC) av = a_val[p];
+        }
+        int inc = len;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int t = __shfl_up(inc, d, 16);
+            if (ql >= d) inc += t;
+        }
+        // the products of these 16 entries as one index space dealt round the 16 lanes: every lane finds the entry
+        // of its product among the 16 offsets, and its loads do not wait for one another (a lane walking its own
+        // row of B would pay one latency per product)
+        const int tot = __shfl(inc, 15, 16);
+        eoff[q][ql] = inc - len;
+        eb0[q][ql] = b0;
+        if (NUMERIC) eav[NUMERIC ? q : 0][ql] = av;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < QC / 16; i++) {
+            const int j = ql + 16 * i;
+            if (j < tot) {
+                int e = 0;
+#pragma unroll
+                for (int h = 8; h > 0; h >>= 1)
+                    if (eoff[q][e + h] <= j) e += h;       // the last entry that starts at or before product j
+                const int src = eb0[q][e] + (j - eoff[q][e]);
+                qkey[run + j] = b_ix[src];
+                if (NUMERIC) qval[run + j] = eav[NUMERIC ? q : 0][e] * b_val[src];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        run += tot;
+    }
+    int n2 = 0;
+    if (small) {
+        n2 = 1;
+        while (n2 < run) n2 <<= 1;
+        for (int i = run + ql; i < n2; i += 16) qkey[i] = KEY_PAD;
+    }
+    int n2max = n2;
+    n2max = max(n2max, __shfl_xor(n2max, 16));
+    n2max = max(n2max, __shfl_xor(n2max, 32));
+    __syncthreads();
+    // every quarter runs the stages of its own network; the barriers are those of the largest
+    for (int k = 2; k <= n2max; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (k <= n2) {
+                for (int t = ql; t < (n2 >> 1); t += 16) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const bool up = (i & k) == 0;
+                    const int ki = qkey[i], kl = qkey[l];
+                    if ((ki > kl) == up) {
+                        qkey[i] = kl;
+                        qkey[l] = ki;
+                        if (NUMERIC) { const double x = qval[i]; qval[i] = qval[l]; qval[l] = x; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int outrun = 0;
+    for (int c0 = 0; c0 < n2max; c0 += 16) {
+        const int t = c0 + ql;
+        const int key = t < n2 ? qkey[t] : KEY_PAD;
+        const bool head = key != KEY_PAD && (t == 0 || qkey[t - 1] != key);
+        const unsigned m = (unsigned)(__ballot(head) >> (q * 16)) & 0xffffu;
+        const int r = outrun + __popc(m & ((1u << ql) - 1u));
+        if (NUMERIC && head) {
+            double s = qval[t];
+            for (int u = t + 1; u < n2 && qkey[u] == key; u++) s += qval[u];
+            c_ix[obase + r] = key;
+            c_val[obase + r] = s;
+        }
+        outrun += __popc(m);
+    }
+    if (!NUMERIC && small && ql == 0) rowcnt[row] = outrun;
 }
 
 // ---------------------------------------------------------------------------
@@ -1805,7 +1940,7 @@ struct Bins {
     int32_t* gslot;      // row -> slot of its per-window counts, or -1
     uint32_t* wcnt;      // [slot][table window] entries of C, written by the symbolic kernel
     long long n_light;   // the last n_light rows of list_w have at most light_max products
-    long long n_s, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
+    long long n_s, n_t, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
 };
@@ -1900,7 +2035,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
-                           out->prod, A->indptr, out->list_s, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
+                           out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
                            ctx->giant_len, out->gslot, out->list_g, counters);
     long long* h = (long long*)ctx->pinned;
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
@@ -1914,6 +2049,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         return SPMM_E_UNSORTED;
     }
     out->n_s = h[CNT_ESC_S];
+    out->n_t = h[CNT_ESC_T];
     out->n_l = h[CNT_ESC_L];
     out->n_m = h[CNT_ESC_M];
     out->n_w = h[CNT_WIN];
@@ -2041,9 +2177,14 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                            B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
                            bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
     }
-    if (bins.n_s > 0)
-        hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)bins.n_s), dim3(64), 0, ctx->stream, bins.list_s,
-                           A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
+    if (bins.n_s > 0)      // the back of the list
+        hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)bins.n_s), dim3(64), 0, ctx->stream,
+                           bins.list_s + ((size_t)A->nrow + 1 - (size_t)bins.n_s), A->indptr, A->indices, A->data, B->indptr, B->indices,
+                           B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
+    if (bins.n_t > 0)      // the front of the list, four rows per wave
+        hipLaunchKernelGGL((k_esc4<4 * ESC_T_CAP, NUMERIC>), dim3((unsigned)((bins.n_t + 3) / 4)), dim3(64), 0, ctx->stream, bins.list_s,
+                           (int)bins.n_t, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip,
+                           row_beg, c_ix, c_val);
     phase_end(ctx, ph_esc);
     HIPCHK(hipGetLastError());
     return SPMM_OK;
@@ -2146,7 +2287,7 @@ extern "C" int spmm_spgemm_numeric_dev(spmm_ctx* ctx, const spmm_csr* A, const s
     if (row_beg == row_end) return SPMM_OK;
     Bins bins;
     CHK(build_bins(ctx, A, B, row_beg, row_end, false, &bins));
-    ARGCHK(bins.n_s + bins.n_l + bins.n_m + bins.n_w + bins.n_g == 0 || (c_indices != nullptr && c_data != nullptr));
+    ARGCHK(bins.n_s + bins.n_t + bins.n_l + bins.n_m + bins.n_w + bins.n_g == 0 || (c_indices != nullptr && c_data != nullptr));
     CHK(launch_rows<true>(ctx, A, B, bins, nullptr, c_indptr, row_beg, c_indices, c_data));
     return SPMM_OK;
 }
