@@ -64,12 +64,16 @@ def product_balanced_bounds(prod, world):
 # matrix of their own (tools/class_cost.py).  The sorted rows are dear per product, the cursor rows per row (a row
 # pays for its column windows whatever its products).  A dense row pays per entry of its row of A as well (the
 # bounds of the window table it reads for the entry): 8.9 ns per entry next to 3.2 ps per product when the row
-# lengths are given (fitted at scales 21 and 22: balance over 8 shards 0.978 and 0.964; scale 20: 0.85); 8.2 ps
-# per product stands for both when they are not.  Only the ratios matter.
+# lengths are given, a quarter more for the rows of more than 8192 entries that several workgroups share (balance
+# over 8 shards: 0.97 at scale 22, 0.99 at scale 21, 0.85 at scale 20, where a shard is a 21 ms step); 8.2 ps per
+# product stands for both when they are not.  Only the ratios matter.
 COST_NS = {"dense": 0.0082, "window": 0.0075, "light": 0.0072, "sorted": 0.0272}
 ROW_NS = {"dense": 0.0, "window": 175.0, "light": 212.0, "sorted": 3.2}
 DENSE_WITH_LENS_NS = 0.0032
 DENSE_ENTRY_NS = 8.9
+GIANT_ENTRIES = 8192      # rows of A above this are shared by several workgroups, each walking the whole table row
+GIANT_FACTOR = 1.25
+ANY_ROW_NS = 1.0          # row products and classification, paid by empty rows too
 
 
 def row_costs(prod, sorted_max, dense_min, light_max=None, lens=None):
@@ -87,9 +91,10 @@ def row_costs(prod, sorted_max, dense_min, light_max=None, lens=None):
     m = prod >= dense_min
     w[m], r[m] = COST_NS["dense"], ROW_NS["dense"]
     if lens is not None:
-        w[m] = DENSE_WITH_LENS_NS
-        r[m] = lens.to(torch.float64)[m] * DENSE_ENTRY_NS
-    return p * w + r * (prod > 0).to(torch.float64)
+        g = torch.where(lens > GIANT_ENTRIES, GIANT_FACTOR, 1.0).to(torch.float64)
+        w[m] = DENSE_WITH_LENS_NS * g[m]
+        r[m] = lens.to(torch.float64)[m] * DENSE_ENTRY_NS * g[m]
+    return p * w + r * (prod > 0).to(torch.float64) + ANY_ROW_NS
 
 
 def cost_balanced_bounds(prod, world, sorted_max, dense_min, light_max=None, lens=None):
