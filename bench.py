@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--cbuf-gib", type=float, default=48.0, help="output buffer (indices+values) per GPU")
+    ap.add_argument("--cbuf-gib", type=float, default=96.0, help="output buffer (indices+values) per GPU")
     ap.add_argument("--cpu-products", type=float, default=1.5e9, help="size of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
