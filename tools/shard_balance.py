@@ -34,7 +34,7 @@ def main():
     _, _, dense_min = ctx.plan_info(n)
     bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min, max(ctx.light_max(n), esc_max),
                                         indptr[1:] - indptr[:-1])
-    cap = int(48 * (1 << 30) / 12)
+    cap = int(96 * (1 << 30) / 12)
     c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
     c_val = torch.empty(cap, dtype=torch.float64, device=dev)
     out = []
