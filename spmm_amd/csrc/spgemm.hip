@@ -5,8 +5,8 @@
 //
 // Rows are binned by their number of intermediate products P_i = sum_k len_B(k):
 //   P_i == 0                 nothing to do
-//   P_i <= ESC_T_CAP (128)   k_esc4: the same expand / bitonic sort / sum in a quarter of a wave, so a
-//                            64-lane workgroup has the gather chains of four rows in flight
+//   P_i <= ESC_T_CAP (64)    k_esc_rows: the same expand / bitonic sort / sum by 8 lanes, so a 64-lane
+//                            workgroup has the gather chains of eight rows in flight
 //   P_i <= ESC_S_CAP (512)   k_esc: one 64-lane workgroup expands the products into LDS, bitonic
 //                            sort by column, runs of equal columns summed
 //   P_i <= ESC_R_CAP (8192)  k_escr: expand (column, index) pairs, stable LSD radix sort in LDS,
@@ -28,7 +28,10 @@ namespace {
 
 constexpr int ESC_S_CAP = 512;
 #ifndef ESC_T_CAP
-#define ESC_T_CAP 128      // rows of at most this many products go four to a wave
+#define ESC_T_CAP 64       // rows of at most this many products go several to a wave,
+#endif
+#ifndef ESC_T_LANES
+#define ESC_T_LANES 8      // this many lanes each (8 x 64 measured best on web-sized graphs; 16 x 64: +5 %, 16 x 128: +10 %)
 #endif
 constexpr int ESC_L_CAP = 4096;
 constexpr int ESC_R_CAP = 8192;         // radix expand-sort-compress: rows with up to this many products and 65535 entries
@@ -293,23 +296,26 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
                                    c_ix, c_val);
 }
 
-// The tiny rows of the smallest bin, four per 64-lane workgroup.  Such a row is a chain of five dependent gathers of a few
-// dozen bytes each (list, row pointers of A, entries of A, row pointers of B, entries of B): latency, not
-// bandwidth, is its cost, so a row of at most CAP/4 products is expanded, sorted and compressed by 16 lanes in
-// a quarter of the LDS arrays and the wave keeps the chains of four rows in flight.
-template <int CAP, bool NUMERIC>
-__global__ void __launch_bounds__(64) k_esc4(const int32_t* __restrict__ list, const int n_list, const int32_t* __restrict__ a_ip,
+// The tiny rows of the smallest bin, 64/L per 64-lane workgroup.  Such a row is a chain of five dependent gathers
+// of a few dozen bytes each (list, row pointers of A, entries of A, row pointers of B, entries of B): latency, not
+// bandwidth, is its cost, so a row of at most QC products is expanded, sorted and compressed by L lanes in its
+// share of the LDS arrays and the wave keeps the chains of 64/L rows in flight.
+template <int L, int QC, bool NUMERIC>
+__global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ list, const int n_list, const int32_t* __restrict__ a_ip,
                                              const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                              const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
                                              const double* __restrict__ b_val, int32_t* __restrict__ rowcnt, const int64_t* __restrict__ c_ip, int32_t row_beg,
                                              int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
-    constexpr int QC = CAP / 4;
+    static_assert(L == 8 || L == 16 || L == 32, "lanes per row");
+    static_assert(QC % L == 0, "whole rounds of products");
+    constexpr int R = 64 / L;             // rows per wave
+    constexpr int CAP = R * QC;
     __shared__ int32_t skey[CAP];
     __shared__ double sval[NUMERIC ? CAP : 1];
-    __shared__ int32_t eoff[4][16], eb0[4][16];
-    __shared__ double eav[NUMERIC ? 4 : 1][16];
-    const int lane = threadIdx.x, q = lane >> 4, ql = lane & 15;
-    const int idx = blockIdx.x * 4 + q;
+    __shared__ int32_t eoff[R][L], eb0[R][L];
+    __shared__ double eav[NUMERIC ? R : 1][L];
+    const int lane = threadIdx.x, q = lane / L, ql = lane % L;
+    const int idx = blockIdx.x * R + q;
     const bool small = idx < n_list;
     const int row = small ? list[idx] : 0;
     int a0 = 0, a1 = 0;
@@ -321,9 +327,9 @@ __global__ void __launch_bounds__(64) k_esc4(const int32_t* __restrict__ list, c
     }
     int32_t* qkey = skey + q * QC;
     double* qval = sval + (NUMERIC ? q * QC : 0);
-    // expand: the 16 lanes of a quarter have the same trip count, and the shuffles stay inside the quarter
+    // expand: the L lanes of a row have the same trip count, and the shuffles stay among them
     int run = 0;
-    for (int e0 = a0; e0 < a1; e0 += 16) {
+    for (int e0 = a0; e0 < a1; e0 += L) {
         const int p = e0 + ql;
         int len = 0, b0 = 0;
         double av = 0.0;
@@ -335,25 +341,25 @@ __global__ void __launch_bounds__(64) k_esc4(const int32_t* __restrict__ list, c
         }
         int inc = len;
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const int t = __shfl_up(inc, d, 16);
+        for (int d = 1; d < L; d <<= 1) {
+            const int t = __shfl_up(inc, d, L);
             if (ql >= d) inc += t;
         }
-        // the products of these 16 entries as one index space dealt round the 16 lanes: every lane finds the entry
-        // of its product among the 16 offsets, and its loads do not wait for one another (a lane walking its own
+        // the products of these L entries as one index space dealt round the L lanes: every lane finds the entry
+        // of its product among the L offsets, and its loads do not wait for one another (a lane walking its own
         // row of B would pay one latency per product)
-        const int tot = __shfl(inc, 15, 16);
+        const int tot = __shfl(inc, L - 1, L);
         eoff[q][ql] = inc - len;
         eb0[q][ql] = b0;
         if (NUMERIC) eav[NUMERIC ? q : 0][ql] = av;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < QC / 16; i++) {
-            const int j = ql + 16 * i;
+        for (int i = 0; i < QC / L; i++) {
+            const int j = ql + L * i;
             if (j < tot) {
                 int e = 0;
 #pragma unroll
-                for (int h = 8; h > 0; h >>= 1)
+                for (int h = L / 2; h > 0; h >>= 1)
                     if (eoff[q][e + h] <= j) e += h;       // the last entry that starts at or before product j
                 const int src = eb0[q][e] + (j - eoff[q][e]);
                 qkey[run + j] = b_ix[src];
@@ -367,17 +373,17 @@ __global__ void __launch_bounds__(64) k_esc4(const int32_t* __restrict__ list, c
     if (small) {
         n2 = 1;
         while (n2 < run) n2 <<= 1;
-        for (int i = run + ql; i < n2; i += 16) qkey[i] = KEY_PAD;
+        for (int i = run + ql; i < n2; i += L) qkey[i] = KEY_PAD;
     }
     int n2max = n2;
-    n2max = max(n2max, __shfl_xor(n2max, 16));
-    n2max = max(n2max, __shfl_xor(n2max, 32));
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) n2max = max(n2max, __shfl_xor(n2max, d));
     __syncthreads();
-    // every quarter runs the stages of its own network; the barriers are those of the largest
+    // every row runs the stages of its own network; the barriers are those of the largest
     for (int k = 2; k <= n2max; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (k <= n2) {
-                for (int t = ql; t < (n2 >> 1); t += 16) {
+                for (int t = ql; t < (n2 >> 1); t += L) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const int l = i | j;
                     const bool up = (i & k) == 0;
@@ -393,11 +399,11 @@ __global__ void __launch_bounds__(64) k_esc4(const int32_t* __restrict__ list, c
         }
     }
     int outrun = 0;
-    for (int c0 = 0; c0 < n2max; c0 += 16) {
+    for (int c0 = 0; c0 < n2max; c0 += L) {
         const int t = c0 + ql;
         const int key = t < n2 ? qkey[t] : KEY_PAD;
         const bool head = key != KEY_PAD && (t == 0 || qkey[t - 1] != key);
-        const unsigned m = (unsigned)(__ballot(head) >> (q * 16)) & 0xffffu;
+        const unsigned m = (unsigned)((__ballot(head) >> (q * L)) & ((1ull << L) - 1ull));
         const int r = outrun + __popc(m & ((1u << ql) - 1u));
         if (NUMERIC && head) {
             double s = qval[t];
@@ -2181,8 +2187,8 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)bins.n_s), dim3(64), 0, ctx->stream,
                            bins.list_s + ((size_t)A->nrow + 1 - (size_t)bins.n_s), A->indptr, A->indices, A->data, B->indptr, B->indices,
                            B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
-    if (bins.n_t > 0)      // the front of the list, four rows per wave
-        hipLaunchKernelGGL((k_esc4<4 * ESC_T_CAP, NUMERIC>), dim3((unsigned)((bins.n_t + 3) / 4)), dim3(64), 0, ctx->stream, bins.list_s,
+    if (bins.n_t > 0)      // the front of the list, several rows per wave
+        hipLaunchKernelGGL((k_esc_rows<ESC_T_LANES, ESC_T_CAP, NUMERIC>), dim3((unsigned)((bins.n_t + 64 / ESC_T_LANES - 1) / (64 / ESC_T_LANES))), dim3(64), 0, ctx->stream, bins.list_s,
                            (int)bins.n_t, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip,
                            row_beg, c_ix, c_val);
     phase_end(ctx, ph_esc);
