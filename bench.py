@@ -158,7 +158,7 @@ def main():
     vA = capi.dev_view(rows_l, n, nnz, indptr[r_lo:], indices, data)
 
     c_ip = torch.empty(rows_l + 1, dtype=torch.int64, device=dev)
-    cap = int(args.cbuf_gib * (1 << 30) / 12)
+    cap = int(args.cbuf_gib * (1 << 30) / 12) // (world if rehearse else 1)    # rehearsing ranks share one GPU
     c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
     c_val = torch.empty(cap, dtype=torch.float64, device=dev)
     setup_s = time.time() - t0
