@@ -57,6 +57,7 @@ struct plan_cache {
     int a_nrow = 0, b_nrow = 0, b_ncol = 0, b_nnz = 0;
     int n_giant = 0;          // dense rows with more than giant_len entries, numbered by the symbolic call
     bool has_wcnt = false;    // the symbolic kernel wrote their per-window counts
+    bool has_table = false;   // the window table of B was built (only products with window rows need it)
 };
 
 struct spmm_ctx {

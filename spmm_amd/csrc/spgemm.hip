@@ -2073,12 +2073,16 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     if (out->n_w > 0)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
-    if (!hit && B->nrow > 0) {
+    // the window table of B, once per pair of matrices and only when some row takes the window kernels
+    bool has_table = hit && pc.has_table;
+    if (!has_table && B->nrow > 0 && (out->n_w > 0 || out->n_g > 0)) {
         int64_t nb = ((int64_t)B->nrow + 3) / 4;
         if (nb > 256 * 32) nb = 256 * 32;
         hipLaunchKernelGGL(k_winptr, dim3((unsigned)nb), dim3(256), 0, ctx->stream, B->nrow, B->indptr, B->indices,
                            out->shift, out->nbase, out->winptr);
+        has_table = true;
     }
+    pc.has_table = has_table;
     pc.a_ip = A->indptr; pc.a_ix = A->indices; pc.b_ip = B->indptr; pc.b_ix = B->indices;
     pc.a_nrow = A->nrow; pc.b_nrow = B->nrow; pc.b_ncol = B->ncol; pc.b_nnz = B->nnz;
     pc.valid = true;
