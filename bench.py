@@ -191,6 +191,7 @@ def main():
         return vsum, hsum
 
     def sync_all():
+        ctx.sync()                 # the library's own runtime handle of the stream
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -199,7 +200,7 @@ def main():
     # ---- warm-up (first one verifies: all-ones inputs => sum of C's values == products) -------
     for w in range(max(args.warmup, 1)):
         vsum, hsum = step(verify=(w == 0))
-        if w == 0 and not os.environ.get("SPMM_WIN_DBG"):
+        if w == 0:
             assert vsum == float(P_local), f"rank {rank}: sum(C) = {vsum} but the rows hold {P_local} products"
     nnz_c_local = state["nnz_c"]
 
@@ -214,7 +215,8 @@ def main():
     ph = {name: ctx.phase_ms(pid) for name, pid in
           [("bins", capi.PH_BINS), ("window_sym", capi.PH_WINDOW_SYM), ("esc_sym", capi.PH_ESC_SYM),
            ("window_num", capi.PH_WINDOW_NUM), ("esc_num", capi.PH_ESC_NUM), ("scan", capi.PH_SCAN),
-           ("dense_num", capi.PH_DENSE_NUM), ("light_num", capi.PH_LIGHT_NUM)]}
+           ("dense_num", capi.PH_DENSE_NUM), ("light_num", capi.PH_LIGHT_NUM), ("dense_sym", capi.PH_DENSE_SYM),
+           ("slab_plan", capi.PH_SLAB_PLAN)]}
     ctx.profile(False)
     stamps = None
     if os.environ.get("SPMM_WIN_STAMPS") == "1":
@@ -261,14 +263,22 @@ def main():
     lens_l = (indptr[r_lo + 1:r_hi + 1] - indptr[r_lo:r_hi]).to(torch.int64)
     rowc = c_ip[1:] - c_ip[:-1]
     light_max = max(ctx.light_max(n), esc_l)
-    masks = {"k_dense": pl >= dense_min, "k_win<numeric>": (pl > light_max) & (pl < dense_min),
+    slab_windows, slab_launches, slab_pieces, slab_widest = ctx.slab_info()
+    dense_name = "k_dense"
+    if slab_windows > 0:       # no window table: every window row went through the launches over B's slab order
+        dense_name, dense_min = "k_slab_acc<numeric>", esc_l + 1
+    masks = {dense_name: pl >= dense_min, "k_win<numeric>": (pl > light_max) & (pl < dense_min),
              "k_win<numeric, 256 threads>": (pl > esc_l) & (pl <= light_max) & (pl < dense_min)}
-    times = {"k_dense": ph["dense_num"], "k_win<numeric>": ph["window_num"], "k_win<numeric, 256 threads>": ph["light_num"]}
+    times = {dense_name: ph["dense_num"], "k_win<numeric>": ph["window_num"], "k_win<numeric, 256 threads>": ph["light_num"]}
     kname = max(times, key=lambda k: times[k][0])
     wmask = masks[kname]
     P_w, nnzA_w, rows_w, nnzC_w = int(pl[wmask].sum()), int(lens_l[wmask].sum()), int(wmask.sum()), int(rowc[wmask].sum())
     bytes_w = 12 * P_w + 20 * nnzA_w + 12 * (rows_w + 1) + 12 * nnzC_w
     t_w_ms = times[kname][0] / args.steps
+    # launches per step: the slab kernel is launched once per column window of B (that holds entries) in every numeric
+    # call; the cursor kernels once per call
+    calls = times[kname][1] // max(args.steps, 1)
+    launches = calls * slab_launches if kname.startswith("k_slab") else calls
     achieved = bytes_w / (t_w_ms * 1e-3) / 1e9 if t_w_ms > 0 else 0.0
     # HBM bytes per launch from PMC counters cannot be collected inside this process: they come from
     # separate rocprofv3 --pmc passes over this same command, stored under profiles/ per workload.
@@ -284,19 +294,20 @@ def main():
             pass
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    algorithmic_bytes_per_launch=bytes_w // max(times[kname][1] // max(args.steps, 1), 1),
+                    algorithmic_bytes_per_launch=bytes_w // max(launches, 1),
                     algorithmic_bytes_per_step=bytes_w, kernel_ms_per_step=round(t_w_ms, 3),
-                    launches_per_step=times[kname][1] // max(args.steps, 1),
+                    launches_per_step=launches, avg_launch_ms=round(t_w_ms / max(launches, 1), 5),
                     rows=rows_w, products=P_w, nnz_c=nnzC_w,
                     numeric_gflops=round(2.0 * P_w / (t_w_ms * 1e-3) / 1e9, 1) if t_w_ms > 0 else None,
-                    table=dict(shift=shift, windows=nbase, dense_min_products=dense_min))
+                    table=dict(shift=shift, windows=nbase, dense_min_products=dense_min),
+                    slab=dict(windows=slab_windows, launched_windows=slab_launches, pieces=slab_pieces, widest_window=slab_widest))
 
     # ---- the two phases as wholes (rank 0's rows), against the same 8 TB/s --------------------------
     # symbolic: 4 B per product (column id of B) + 12 B per entry of A + row pointers + 8 B per row count;
     # numeric: 12 B per product + 20 B per entry of A + row pointers of A and C + 12 B per entry of C.
     nnzA_l, nnzC_l = int(lens_l.sum()), int(rowc.sum())
     t_num = sum(ph[k][0] for k in ("dense_num", "window_num", "light_num", "esc_num")) / args.steps
-    t_sym = sum(ph[k][0] for k in ("window_sym", "esc_sym", "scan")) / args.steps
+    t_sym = sum(ph[k][0] for k in ("window_sym", "esc_sym", "scan", "dense_sym", "slab_plan")) / args.steps
     b_num = 12 * P_local + 20 * nnzA_l + 12 * (rows_l + 1) + 12 * nnzC_l
     b_sym = 4 * P_local + 12 * nnzA_l + 4 * (rows_l + 1) + 8 * rows_l
     phase_totals = {

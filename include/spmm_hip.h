@@ -78,8 +78,10 @@ enum {
     SPMM_PH_PACK = 10,       /* block row gather + 8-row interleave (serial_newblock_clock.cpp:336-399) */
     SPMM_PH_RENUMBER = 11,   /* first-touch renumbering (serial_newblock_clock.cpp:187) */
     SPMM_PH_WBSEQ = 12,      /* write-back sequence (wbsort.h) */
-    SPMM_PH_DENSE_NUM = 13,         /* numeric over the product-heaviest rows (dense fp64 accumulators) */
+    SPMM_PH_DENSE_NUM = 13,         /* numeric over the product-heaviest rows (one launch per column window of B) */
     SPMM_PH_LIGHT_NUM = 14,         /* numeric over the lightest window rows (256-thread cursor workgroups) */
+    SPMM_PH_DENSE_SYM = 15,         /* symbolic over the product-heaviest rows */
+    SPMM_PH_SLAB_PLAN = 16,         /* B into column-window (slab) order, once per pair of matrices */
     SPMM_PH_COUNT = 32
 };
 int spmm_ctx_profile(spmm_ctx* ctx, int enable);
@@ -93,6 +95,14 @@ void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
  * *dense_min_products intermediate products take the dense-accumulator numeric kernel (INT64_MAX
  * when that kernel is switched off).  Diagnostic, no counterpart in the reference. */
 int spmm_spgemm_plan_info(spmm_ctx* ctx, int32_t b_ncol, int32_t* shift, int32_t* nbase, int64_t* dense_min_products);
+/* The slab order of B that the last symbolic call on ctx built for its heaviest rows (all zero when it had none):
+ * column windows, windows that hold entries of B (one kernel launch each per call), pieces (runs of one row of B
+ * inside one window) and the widest window in columns.  spmm_slab_windows is the host rule that cuts the windows
+ * from the entries of B per block of 64 columns (a window ends before the block that would take it past smax
+ * entries or wmax columns); wb receives *nwin + 1 boundaries.  Diagnostic, no counterpart in the reference. */
+int spmm_spgemm_slab_info(spmm_ctx* ctx, int32_t* windows, int32_t* launched_windows, int64_t* pieces, int32_t* widest);
+int spmm_slab_windows(const uint32_t* blk, int32_t nblk, int32_t ncol, int32_t wmax, int64_t smax, int32_t* wb, int32_t cap,
+                      int32_t* nwin);
 /* Window rows of A with at most *light_max_products intermediate products take the 256-thread form of the
  * cursor kernel (0: none).  Diagnostic, no counterpart in the reference. */
 int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* light_max_products);

@@ -19,6 +19,18 @@ I32, I64, F64 = np.int32, np.int64, np.float64
 PH_BINS, PH_WINDOW_SYM, PH_ESC_SYM, PH_WINDOW_NUM, PH_ESC_NUM, PH_SCAN, PH_CSR_BUILD = range(7)
 PH_DENSE_NUM = 13
 PH_LIGHT_NUM = 14
+PH_DENSE_SYM = 15
+PH_SLAB_PLAN = 16
+
+
+def slab_windows(blk, ncol, wmax, smax):
+    """Column-window boundaries from the entries per block of 64 columns (host rule of the slab order)."""
+    blk = np.ascontiguousarray(blk, dtype=np.uint32)
+    wb = np.empty(blk.size + 2, I32)
+    n = C.c_int32()
+    _chk(lib().spmm_slab_windows(_p(blk), C.c_int32(blk.size), C.c_int32(ncol), C.c_int32(wmax), C.c_int64(smax), _p(wb),
+                                 C.c_int32(wb.size), C.byref(n)))
+    return wb[:n.value + 1].copy()
 
 
 def bin_limits():
@@ -139,6 +151,13 @@ class Context:
         sh, nb, dm = C.c_int32(), C.c_int32(), C.c_int64()
         _chk(lib().spmm_spgemm_plan_info(self._h, C.c_int32(int(b_ncol)), C.byref(sh), C.byref(nb), C.byref(dm)))
         return int(sh.value), int(nb.value), int(dm.value)
+
+    def slab_info(self):
+        """(windows, windows with entries of B = launches per call, pieces, widest window) of the slab order the last
+        symbolic call built."""
+        nw, nl, np_, wd = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+        _chk(lib().spmm_spgemm_slab_info(self._h, C.byref(nw), C.byref(nl), C.byref(np_), C.byref(wd)))
+        return int(nw.value), int(nl.value), int(np_.value), int(wd.value)
 
     def light_max(self, b_ncol):
         """Window rows with at most this many products take the 256-thread cursor workgroups."""

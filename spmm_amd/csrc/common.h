@@ -45,24 +45,51 @@ enum ws_slot {
     WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_ESC_M, WS_LIST_GIANT, WS_GSLOT, WS_WCNT, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
     WS_WINPTR, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_P0, WS_P1, WS_P2, WS_P3, WS_P4, WS_P5, WS_P6, WS_P7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
+    // slab order of B for the window launches over the heaviest rows: kept between symbolic and numeric (PERM .. SLOTROW), scratch of the build (T0 .. T5)
+    WS_SL_PERM, WS_SL_COL, WS_SL_VAL, WS_SL_PIECE, WS_SL_PFIRST, WS_SL_PFIRSTW, WS_SL_CUR, WS_SL_NW, WS_SL_CNT, WS_SL_WB, WS_SL_LUT, WS_SL_SLOTROW, WS_SL_EBASE, WS_SL_WROW, WS_SL_ITEMS, WS_SL_ITEMA, WS_SL_RCOUNT, WS_SL_TICKET, WS_SL_AROW0, WS_SL_OBASE, WS_SL_CNTR,
+    WS_SL_T0, WS_SL_T1, WS_SL_T2, WS_SL_T3, WS_SL_T4, WS_SL_T5,
     WS_NSLOTS
 };
 
 struct phase_rec { int phase; hipEvent_t e0, e1; };
 
-// What the last product call computed for (A, B): row products and B's window-pointer table.
+// What the last symbolic call computed for (A, B): row products, numbered rows, B's window-pointer table or slab
+// order.  A numeric call may use it when the digests of its own structure arrays are the same.
 struct plan_cache {
     bool valid = false;
-    const void *a_ip = nullptr, *a_ix = nullptr, *b_ip = nullptr, *b_ix = nullptr;
-    int a_nrow = 0, b_nrow = 0, b_ncol = 0, b_nnz = 0;
-    int n_giant = 0;          // dense rows with more than giant_len entries, numbered by the symbolic call
-    bool has_wcnt = false;    // the symbolic kernel wrote their per-window counts
+    unsigned long long dig_a = 0, dig_b = 0;   // content digests of (indptr, indices) of A and of B
+    int a_nrow = 0, a_nnz = 0, b_nrow = 0, b_ncol = 0, b_nnz = 0;
+    int n_giant = 0;          // rows numbered by the symbolic call (dense rows with very many entries; with the slab order all window rows)
+    bool has_wcnt = false;    // the symbolic kernel wrote the numbered rows' per-window counts
     bool has_table = false;   // the window table of B was built (only products with window rows need it)
+    bool has_slab = false;    // the slab order of B was built (likewise)
+    bool slab = false;        // the plan is one without the window table
+};
+
+// B in slab order (slab.hip): column windows, entries sorted by window, pieces with links.
+struct slab_plan {
+    bool valid = false, has_values = false;
+    int nwin = 0, nslots = 0;
+    int64_t npieces = 0, nnz = 0;
+    std::vector<int32_t> wb;        // first column of every window, then ncol
+    std::vector<int64_t> entries;   // entries of B per window
+    uint16_t* col = nullptr;        // column offset inside the window, slab order
+    double* val = nullptr;          // values, slab order (loaded by every numeric call)
+    uint4* pieces = nullptr;        // {first slab position, length, next piece of the row, its window}
+    uint32_t* pfirst = nullptr;     // first piece of every row of B
+    uint16_t* pfirst_w = nullptr;   // and its window
+    uint32_t* perm = nullptr;       // slab position -> entry of B
+    uint32_t* cnt = nullptr;        // [window][slot] entries of C before this window in the slot's row
 };
 
 struct spmm_ctx {
     bool profile = false;
     plan_cache plan;
+    slab_plan slab;
+    int slab_wmax = 15360;          // widest column window (dense fp64 accumulators + flags in LDS)
+    int slab_threads = 512;         // threads of a workgroup of the accumulate kernels (256 or 512)
+    int slab_dense_cols = 15360;    // windows up to this width keep dense accumulators, wider ones the compact form
+    long long slab_smax = 4194304;  // entries of B per window (its slab: 10 bytes an entry); fewer, heavier windows measured faster than L2-sized ones
     bool win_stamps = false;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int adaptive = 1;       // numeric k_win: window widths follow the row's product distribution
     int sym_cfg = 0;        // symbolic window kernel: 0 = k_symd (tiered sweep), 1 = k_win
@@ -71,6 +98,8 @@ struct spmm_ctx {
     int giant_len = 8192;   // dense rows with more entries of A than this are the ones that get split
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
+    int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
+    long long table_max_bytes = 16ll << 30;
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse
@@ -87,6 +116,14 @@ struct spmm_ctx {
 };
 
 int ws_get(spmm_ctx* ctx, int slot, size_t bytes, void** out);
+
+// slab.hip: the heaviest rows of the product, one kernel launch per column window
+int slab_build(spmm_ctx* ctx, const spmm_csr* B);
+int slab_load_values(spmm_ctx* ctx, const spmm_csr* B);
+int slab_symbolic(spmm_ctx* ctx, const spmm_csr* A, const int32_t* list, int n, const int32_t* gslot, const int32_t* slot_row,
+                  int nslots, int32_t* rowcnt);
+int slab_numeric(spmm_ctx* ctx, const spmm_csr* A, const int32_t* list, int n, const int32_t* gslot, const int64_t* c_ip,
+                 int32_t row_beg, int32_t* c_ix, double* c_val);
 
 // Per-phase GPU timing (hipEvents on the context's stream), active only while profiling is on.
 int phase_begin(spmm_ctx* ctx, int phase);   // returns a record index or -1

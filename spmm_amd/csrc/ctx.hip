@@ -41,13 +41,21 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     c->own_stream = true;
     if (const char* e = getenv("SPMM_DENSE_MIN")) c->dense_min = atoll(e);
     if (const char* e = getenv("SPMM_SYM_CFG")) c->sym_cfg = atoi(e);
+    if (const char* e = getenv("SPMM_LIGHT_MAX")) c->light_max = atoll(e);
     if (const char* e = getenv("SPMM_GIANT_TASKS")) c->giant_tasks = atoi(e) > 1 ? atoi(e) : 2;
     if (const char* e = getenv("SPMM_GIANT_CHUNK")) c->giant_chunk = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("SPMM_LIGHT_MAX")) c->light_max = atoll(e);
     if (const char* e = getenv("SPMM_SPLIT_GIANT")) c->split_giant = atoi(e);
     if (const char* e = getenv("SPMM_GIANT_LEN")) c->giant_len = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("SPMM_SLAB")) c->slab_mode = atoi(e);
+    if (const char* e = getenv("SPMM_TABLE_MAX_GIB")) c->table_max_bytes = (long long)(atof(e) * (double)(1ll << 30));
+    if (const char* e = getenv("SPMM_SLAB_WMAX")) { int v = atoi(e) & ~63; c->slab_wmax = v < 64 ? 64 : v > 15360 ? 15360 : v; }
+    if (const char* e = getenv("SPMM_SLAB_THREADS")) c->slab_threads = atoi(e) == 256 ? 256 : 512;
+    if (const char* e = getenv("SPMM_SLAB_DENSE_COLS")) c->slab_dense_cols = atoi(e) < 0 ? 0 : atoi(e);
+    if (const char* e = getenv("SPMM_SLAB_SMAX")) { long long v = atoll(e); c->slab_smax = v < 1024 ? 1024 : v; }
     if (const char* e = getenv("SPMM_ADAPTIVE")) c->adaptive = atoi(e);
-    if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);
+#ifdef SPMM_DIAG
+    if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);   // diagnostic builds only: results are wrong when nonzero
+#endif
     if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e) != 0;
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);

@@ -48,7 +48,7 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_N = 12 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_N = 14 };
 
 // ---------------------------------------------------------------------------
 // P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
                                                           int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
                                                           long long dense_thr, long long light_max, int giant_mode, int giant_len,
                                                           int32_t* __restrict__ gslot, int32_t* __restrict__ list_g,
+                                                          int slab, int32_t* __restrict__ slot_row, uint32_t* __restrict__ key_g,
                                                           long long* __restrict__ counters) {
     constexpr int NW = CLS_THREADS / 64;
     enum { C_NONE = 0, C_G = 1, C_M = 2, C_W = 3, C_L = 4, C_S = 5, C_T = 6, C_DENSE = 7, C_LIGHT = 8, C_N = 9 };
@@ -158,9 +159,17 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
         // (giant_mode 1) numbers them; a numeric call that can use the symbolic call's per-window counts
         // (giant_mode 2) takes them out of the window list and splits each over several workgroups.
         const bool is_win = p > ESC_R_CAP || (p > ESC_S_CAP && many_entries);   // the row takes the window kernels
-        if (giant_mode == 1 && is_win && p >= dense_thr && len_a > giant_len)
+        // Without the window table of B (slab != 0) every window row takes the launches over B's slab order: the
+        // symbolic call numbers them all (giant_mode 1) and later calls on the same matrices keep the numbers.
+        if (slab && is_win && giant_mode == 1) {
+            const int slot = (int)atomicAdd((unsigned long long*)&counters[CNT_GIANT_ALL], 1ull);
+            gslot[row] = slot;
+            slot_row[slot] = (int32_t)row;
+        }
+        if (!slab && giant_mode == 1 && is_win && p >= dense_thr && len_a > giant_len)
             gslot[row] = (int)atomicAdd((unsigned long long*)&counters[CNT_GIANT_ALL], 1ull);
-        if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) cat = C_G;
+        if (slab && is_win) cat = C_G;
+        else if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) cat = C_G;
         else if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) cat = C_M;
         else if (is_win) {
             cat = C_W;
@@ -195,8 +204,10 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
     __syncthreads();
     if (cat != C_NONE) {
         const int at = (int)gbase[cat] + wcnt[wv][cat] + rank;
-        if (cat == C_G) list_g[at] = (int32_t)row;
-        else if (cat == C_M) list_m[at] = (int32_t)row;
+        if (cat == C_G) {
+            list_g[at] = (int32_t)row;
+            key_g[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);
+        } else if (cat == C_M) list_m[at] = (int32_t)row;
         else if (cat == C_L) list_l[at] = (int32_t)row;
         else if (cat == C_T) list_s[at] = (int32_t)row;             // the tiny rows fill the list from the front,
         else if (cat == C_S) list_s[s_top - at] = (int32_t)row;     // the other rows of the smallest bin from the back
@@ -207,6 +218,24 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
     }
     long long s = wave_reduce_sum(p);
     if (lane == 0 && s) atomicAdd((unsigned long long*)&counters[CNT_PRODUCTS], (unsigned long long)s);
+}
+
+// Content digest of an int32 array (row pointers, column ids): what a numeric call compares with the symbolic
+// call's to know that the kept row products, slots and slab order belong to the matrices it was given.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+__global__ void __launch_bounds__(256) k_struct_digest(const int32_t* __restrict__ a, int64_t n, unsigned long long salt,
+                                                       unsigned long long* __restrict__ out) {
+    unsigned long long h = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        h += mix64((unsigned long long)(uint32_t)a[i] + ((unsigned long long)i + salt) * 0x9e3779b97f4a7c15ull);
+    h = wave_reduce_sum(h);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
 }
 
 // ---------------------------------------------------------------------------
@@ -836,8 +865,14 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                                                  const int64_t* __restrict__ prod, int32_t* __restrict__ rowcnt,
                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val,
-                                                 unsigned long long* __restrict__ stamps, int dbg, int adaptive) {
+                                                 unsigned long long* __restrict__ stamps, int dbg_arg, int adaptive) {
     static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
+#ifdef SPMM_DIAG
+    const int dbg = dbg_arg;       // timing experiments of the diagnostic build (results are wrong when nonzero)
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     // the 256-thread form serves rows of at most 65535 products: ranks fit 16 bits, and two workgroups fit a CU
     constexpr bool PRE16 = NUMERIC && THREADS == 256;
     using pre_t = typename std::conditional<PRE16, uint16_t, uint32_t>::type;
@@ -1452,7 +1487,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
                                                    const int32_t* __restrict__ winptr, int nbase, int shift,
                                                    const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg,
+                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg_arg,
                                                    unsigned long long* __restrict__ stamps, const int32_t* __restrict__ list_g,
                                                    int n_shared, int ntask_shared, int chunk,
                                                    const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt) {
@@ -1460,6 +1495,12 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     // t of a row takes the table windows t, t + ntask, ... (in chunks of `chunk`) and finds the place of a
     // window's entries in the row of C from the per-window counts of the symbolic phase (at most THREADS
     // table windows).  The other workgroups take one row of `list` each.
+#ifdef SPMM_DIAG
+    const int dbg = dbg_arg >= 4 && dbg_arg <= 6 ? dbg_arg : 0;   // diagnostic build: entries per wave and pass forced to 2^dbg
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     const bool shared = blockIdx.x < (unsigned)n_shared;
     const int ntask = shared ? ntask_shared : 1;
     constexpr int NW = THREADS / 64;
@@ -1936,19 +1977,24 @@ int check_csr_args(const spmm_csr* M) {
     return SPMM_OK;
 }
 
-// Shared front end of symbolic and numeric: P_i, bins, heaviest-first order of the window rows,
-// and the window-pointer table of B.  P_i and the table depend only on (A, B) and are kept in the
-// context between calls: symbolic always recomputes them, numeric reuses them when it is called
-// with the same device arrays as the last symbolic call (the normal sequence).
+// Shared front end of symbolic and numeric: P_i, bins, heaviest-first order of the window rows, and what the
+// window kernels read of B: the window-pointer table, or (when that table is switched off or would not fit) B's
+// slab order for the launches of slab.hip.  All of it depends only on the structure of (A, B) and is kept in
+// the context by a symbolic call; a numeric call reuses it when the content digests of its four structure
+// arrays equal the symbolic call's, and otherwise rebuilds what it needs for its own rows.
 struct Bins {
     int64_t* prod;
-    int32_t *list_s, *list_l, *list_m, *list_w, *list_g;   // list_g: dense rows split into window ranges
+    int32_t *list_s, *list_l, *list_m, *list_w, *list_g;   // list_g: dense rows split into window ranges, or (slab) all window rows
     int32_t* gslot;      // row -> slot of its per-window counts, or -1
+    int32_t* slot_row;   // slot -> row (slab)
     uint32_t* wcnt;      // [slot][table window] entries of C, written by the symbolic kernel
     long long n_light;   // the last n_light rows of list_w have at most light_max products
     long long n_s, n_t, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
+    bool slab;           // the window rows take the launches over B's slab order
+    int nslots;          // (slab) numbered rows
+    bool rebuilt;        // (slab) a numeric call found no matching plan: the slots are this call's own, without counts yet
 };
 
 // Column width of a table window: 2^14 columns (the width of the dense accumulators) while that
@@ -1975,46 +2021,71 @@ long long dense_threshold(const spmm_ctx* ctx, int nbase) {
     return d > 0xffffffffll ? 0xffffffffll : d;   // the sort key of the row order saturates there
 }
 
-int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, bool fresh,
-               Bins* out) {
+enum { BINS_PRODUCTS = 0, BINS_SYMBOLIC = 1, BINS_NUMERIC = 2 };
+
+int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, int mode, Bins* out) {
     const int32_t nrow = A->nrow;
+    const bool fresh = mode != BINS_NUMERIC;
     long long* counters;
     int ph = phase_begin(ctx, SPMM_PH_BINS);
     plan_cache& pc = ctx->plan;
-    const bool hit = !fresh && pc.valid && pc.a_ip == A->indptr && pc.a_ix == A->indices && pc.b_ip == B->indptr &&
-                     pc.b_ix == B->indices && pc.a_nrow == A->nrow && pc.b_nrow == B->nrow && pc.b_ncol == B->ncol &&
-                     pc.b_nnz == B->nnz;
-    pc.valid = false;
     CHK(ws(ctx, WS_COUNTERS, CNT_N, &counters));
     CHK(ws(ctx, WS_PROD, (size_t)nrow + 1, &out->prod));
     CHK(ws(ctx, WS_LIST_ESC_S, (size_t)nrow + 1, &out->list_s));
     CHK(ws(ctx, WS_LIST_ESC_L, (size_t)nrow + 1, &out->list_l));
     CHK(ws(ctx, WS_LIST_ESC_M, (size_t)nrow + 1, &out->list_m));
-    int32_t* list_w0;
-    uint32_t *key_w0, *key_w1;
+    int32_t *list_w0, *list_g0;
+    uint32_t *key_w0, *key_w1, *key_g0, *key_g1;
     CHK(ws(ctx, WS_MISC0, (size_t)nrow + 1, &list_w0));
     CHK(ws(ctx, WS_MISC1, (size_t)nrow + 1, &key_w0));
     CHK(ws(ctx, WS_MISC2, (size_t)nrow + 1, &key_w1));
+    CHK(ws(ctx, WS_MISC4, (size_t)nrow + 1, &list_g0));
+    CHK(ws(ctx, WS_MISC5, (size_t)nrow + 1, &key_g0));
+    CHK(ws(ctx, WS_MISC6, (size_t)nrow + 1, &key_g1));
     CHK(ws(ctx, WS_LIST_WIN, (size_t)nrow + 1, &out->list_w));
     CHK(ws(ctx, WS_LIST_GIANT, (size_t)nrow + 1, &out->list_g));
     CHK(ws(ctx, WS_GSLOT, (size_t)nrow + 1, &out->gslot));
+    CHK(ws(ctx, WS_SL_SLOTROW, (size_t)nrow + 1, &out->slot_row));
     out->shift = table_shift(B->ncol, ctx->dense_min);
     out->nbase = (int)(((int64_t)B->ncol + (1ll << out->shift) - 1) >> out->shift);
     if (out->nbase < 1) out->nbase = 1;
+    // The window table holds nbase + 1 positions per row of B.  Past the budget (or when switched off) the window
+    // rows take the launches over B's slab order instead, whose structures are O(nnz(B)).
     const size_t table_elems = (size_t)B->nrow * ((size_t)out->nbase + 1);
-    if (table_elems * 4 > ((size_t)96 << 30)) {
-        spmm_set_error("spgemm: window table of B would need %zu GiB", (table_elems * 4) >> 30);
-        return SPMM_E_CAPACITY;
-    }
-    CHK(ws(ctx, WS_WINPTR, table_elems + 1, &out->winptr));
+    const bool slab = ctx->slab_mode > 0 || (ctx->slab_mode < 0 && table_elems * 4 > (size_t)ctx->table_max_bytes);
+    out->slab = slab;
     HIPCHK(hipMemsetAsync(counters, 0, sizeof(long long) * CNT_N, ctx->stream));
+    long long* h = (long long*)ctx->pinned;
+    // content digests of the structure arrays
+    {
+        unsigned long long* dg = (unsigned long long*)counters;
+        auto digest = [&](const int32_t* a, int64_t n, unsigned long long salt, int slot) {
+            if (n <= 0) return;
+            int64_t g = (n + 255) / 256;
+            if (g > 256 * 16) g = 256 * 16;
+            hipLaunchKernelGGL(k_struct_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, a, n, salt, dg + slot);
+        };
+        digest(A->indptr, (int64_t)A->nrow + 1, 0x1000000000ull, CNT_DIG_A);
+        digest(A->indices, A->nnz, 0x2000000000ull, CNT_DIG_A);
+        digest(B->indptr, (int64_t)B->nrow + 1, 0x1000000000ull, CNT_DIG_B);
+        digest(B->indices, B->nnz, 0x2000000000ull, CNT_DIG_B);
+    }
+    bool hit = false;
+    if (!fresh && pc.valid && pc.slab == slab && pc.a_nrow == A->nrow && pc.a_nnz == A->nnz && pc.b_nrow == B->nrow &&
+        pc.b_ncol == B->ncol && pc.b_nnz == B->nnz) {
+        HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        hit = (unsigned long long)h[CNT_DIG_A] == pc.dig_a && (unsigned long long)h[CNT_DIG_B] == pc.dig_b;
+    }
+    pc.valid = false;
+    out->rebuilt = !fresh && !hit;
     if (!hit && nrow > 0) {
         int64_t nb = ((int64_t)nrow + 15) / 16;
         if (nb > 256 * 64) nb = 256 * 64;
         hipLaunchKernelGGL(k_row_products, dim3((unsigned)nb), dim3(256), 0, ctx->stream, nrow, B->nrow, A->indptr,
                            A->indices, B->indptr, out->prod, counters);
     }
-    if (fresh && B->nnz > 0) {
+    if (!hit && B->nnz > 0) {
         int64_t g = ((int64_t)B->nnz + 255) / 256;
         if (g > 256 * 16) g = 256 * 16;
         hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->nrow, B->ncol, B->indptr,
@@ -2027,23 +2098,24 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     // than 65535 (16-bit ranks).
     long long light_max = ctx->light_max >= 0 ? ctx->light_max : 128ll * out->nbase;
     if (light_max > 65535) light_max = 65535;
-    // the symbolic call numbers the giant rows; a numeric call on the same matrices splits them when the
-    // symbolic kernel left their per-window counts
+    // Numbered rows.  With the table: the symbolic call numbers the dense rows with very many entries, and a numeric
+    // call on the same matrices splits them when the symbolic kernel left their per-window counts.  With the slab
+    // order: every window row is numbered, by the symbolic call or, failing a matching one, by the numeric call.
     const bool can_count = ctx->split_giant && ctx->sym_cfg == 0 && out->shift <= 20 && out->nbase >= 2 * ctx->giant_tasks * ctx->giant_chunk &&
                            out->nbase <= 1024;
-    const int giant_mode = fresh ? (can_count ? 1 : 0) : (hit && pc.has_wcnt ? 2 : 0);
+    int giant_mode;
+    if (slab) giant_mode = hit ? 2 : 1;
+    else giant_mode = fresh ? (can_count ? 1 : 0) : (hit && pc.has_wcnt ? 2 : 0);
+    if (mode == BINS_PRODUCTS) giant_mode = 0;
     if (!hit) {
         pc.has_wcnt = false;
         pc.n_giant = 0;
     }
-    if (fresh) {
-        HIPCHK(hipMemsetAsync(out->gslot, 0xff, sizeof(int32_t) * ((size_t)nrow + 1), ctx->stream));
-    }
+    if (!hit) HIPCHK(hipMemsetAsync(out->gslot, 0xff, sizeof(int32_t) * ((size_t)nrow + 1), ctx->stream));
     if (nr > 0)
         hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
                            out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
-                           ctx->giant_len, out->gslot, out->list_g, counters);
-    long long* h = (long long*)ctx->pinned;
+                           ctx->giant_len, out->gslot, list_g0, (slab && mode != BINS_PRODUCTS) ? 1 : 0, out->slot_row, key_g0, counters);
     HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (h[CNT_BAD]) {
@@ -2064,8 +2136,15 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->n_g = h[CNT_GIANT];
     out->products = h[CNT_PRODUCTS];
     if (giant_mode == 1) pc.n_giant = (int)h[CNT_GIANT_ALL];
+    out->nslots = pc.n_giant;
+    const unsigned long long dig_a = (unsigned long long)h[CNT_DIG_A], dig_b = (unsigned long long)h[CNT_DIG_B];
     out->wcnt = nullptr;
-    if (pc.n_giant > 0 && giant_mode != 0) {
+    out->winptr = nullptr;
+    if (mode == BINS_PRODUCTS) {
+        phase_end(ctx, ph);
+        return SPMM_OK;
+    }
+    if (!slab && pc.n_giant > 0 && giant_mode != 0) {
         CHK(ws(ctx, WS_WCNT, (size_t)pc.n_giant * out->nbase + 1, &out->wcnt));
         if (giant_mode == 1) {
             HIPCHK(hipMemsetAsync(out->wcnt, 0, sizeof(uint32_t) * ((size_t)pc.n_giant * out->nbase + 1), ctx->stream));
@@ -2073,20 +2152,35 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     if (out->n_w > 0)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
-    // the window table of B, once per pair of matrices and only when some row takes the window kernels
+    if (out->n_g > 0)
+        CHK(dev_radix_sort_pairs(ctx, key_g0, (uint32_t*)list_g0, key_g1, (uint32_t*)out->list_g, out->n_g, 32));
+    // the window table of B, once per pair of matrices and only when some row takes the table's kernels
     bool has_table = hit && pc.has_table;
-    if (!has_table && B->nrow > 0 && (out->n_w > 0 || out->n_g > 0)) {
-        int64_t nb = ((int64_t)B->nrow + 3) / 4;
-        if (nb > 256 * 32) nb = 256 * 32;
-        hipLaunchKernelGGL(k_winptr, dim3((unsigned)nb), dim3(256), 0, ctx->stream, B->nrow, B->indptr, B->indices,
-                           out->shift, out->nbase, out->winptr);
-        has_table = true;
+    if (!slab && (out->n_w > 0 || out->n_g > 0)) {
+        CHK(ws(ctx, WS_WINPTR, table_elems + 1, &out->winptr));
+        if (!has_table && B->nrow > 0) {
+            int64_t nb = ((int64_t)B->nrow + 3) / 4;
+            if (nb > 256 * 32) nb = 256 * 32;
+            hipLaunchKernelGGL(k_winptr, dim3((unsigned)nb), dim3(256), 0, ctx->stream, B->nrow, B->indptr, B->indices,
+                               out->shift, out->nbase, out->winptr);
+            has_table = true;
+        }
+    }
+    phase_end(ctx, ph);
+    // the slab order of B, likewise
+    bool has_slab = hit && pc.has_slab;
+    if (slab && out->n_g > 0 && !has_slab) {
+        int ps = phase_begin(ctx, SPMM_PH_SLAB_PLAN);
+        CHK(slab_build(ctx, B));
+        phase_end(ctx, ps);
+        has_slab = true;
     }
     pc.has_table = has_table;
-    pc.a_ip = A->indptr; pc.a_ix = A->indices; pc.b_ip = B->indptr; pc.b_ix = B->indices;
-    pc.a_nrow = A->nrow; pc.b_nrow = B->nrow; pc.b_ncol = B->ncol; pc.b_nnz = B->nnz;
-    pc.valid = true;
-    phase_end(ctx, ph);
+    pc.has_slab = has_slab;
+    pc.slab = slab;
+    pc.dig_a = dig_a; pc.dig_b = dig_b;
+    pc.a_nrow = A->nrow; pc.a_nnz = A->nnz; pc.b_nrow = B->nrow; pc.b_ncol = B->ncol; pc.b_nnz = B->nnz;
+    pc.valid = fresh || hit;       // a numeric call that had to rebuild leaves nothing a later call could trust
     HIPCHK(hipGetLastError());
     return SPMM_OK;
 }
@@ -2116,6 +2210,18 @@ template <bool NUMERIC>
 int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins_in, int32_t* rowcnt,
                 const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
     Bins bins = bins_in;
+    if (bins.slab && bins.n_g > 0) {
+        // no window table: every window row goes through the launches over B's slab order, one per column window
+        int phd = phase_begin(ctx, NUMERIC ? SPMM_PH_DENSE_NUM : SPMM_PH_DENSE_SYM);
+        if (NUMERIC) {
+            CHK(slab_load_values(ctx, B));
+            CHK(slab_numeric(ctx, A, bins.list_g, (int)bins.n_g, bins.gslot, c_ip, row_beg, c_ix, c_val));
+        } else {
+            CHK(slab_symbolic(ctx, A, bins.list_g, (int)bins.n_g, bins.gslot, bins.slot_row, bins.nslots, rowcnt));
+        }
+        phase_end(ctx, phd);
+        bins.n_g = 0;
+    }
     if (NUMERIC && (bins.n_dense > 0 || bins.n_g > 0)) {
         int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
@@ -2253,7 +2359,7 @@ extern "C" int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spm
     ARGCHK(A->ncol == B->nrow);
     HIPCHK(hipSetDevice(ctx->device));
     Bins bins;
-    CHK(build_bins(ctx, A, B, 0, A->nrow, true, &bins));
+    CHK(build_bins(ctx, A, B, 0, A->nrow, BINS_PRODUCTS, &bins));
     if (prod && A->nrow > 0)
         HIPCHK(hipMemcpyAsync(prod, bins.prod, sizeof(int64_t) * (size_t)A->nrow, hipMemcpyDeviceToDevice, ctx->stream));
     if (total) *total = bins.products;
@@ -2268,7 +2374,7 @@ extern "C" int spmm_spgemm_symbolic_dev(spmm_ctx* ctx, const spmm_csr* A, const 
     ARGCHK(A->ncol == B->nrow);
     HIPCHK(hipSetDevice(ctx->device));
     Bins bins;
-    CHK(build_bins(ctx, A, B, 0, A->nrow, true, &bins));
+    CHK(build_bins(ctx, A, B, 0, A->nrow, BINS_SYMBOLIC, &bins));
     int32_t* rowcnt;
     CHK(ws(ctx, WS_ROWCNT, (size_t)A->nrow + 1, &rowcnt));
     HIPCHK(hipMemsetAsync(rowcnt, 0, sizeof(int32_t) * ((size_t)A->nrow + 1), ctx->stream));
@@ -2296,8 +2402,14 @@ extern "C" int spmm_spgemm_numeric_dev(spmm_ctx* ctx, const spmm_csr* A, const s
     HIPCHK(hipSetDevice(ctx->device));
     if (row_beg == row_end) return SPMM_OK;
     Bins bins;
-    CHK(build_bins(ctx, A, B, row_beg, row_end, false, &bins));
+    CHK(build_bins(ctx, A, B, row_beg, row_end, BINS_NUMERIC, &bins));
     ARGCHK(bins.n_s + bins.n_t + bins.n_l + bins.n_m + bins.n_w + bins.n_g == 0 || (c_indices != nullptr && c_data != nullptr));
+    if (bins.slab && bins.rebuilt && bins.n_g > 0) {
+        // no symbolic call on these matrices left its per-window counts: count the window rows of this call again
+        int32_t* rowcnt;
+        CHK(ws(ctx, WS_ROWCNT, (size_t)A->nrow + 1, &rowcnt));
+        CHK(slab_symbolic(ctx, A, bins.list_g, (int)bins.n_g, bins.gslot, bins.slot_row, bins.nslots, rowcnt));
+    }
     CHK(launch_rows<true>(ctx, A, B, bins, nullptr, c_indptr, row_beg, c_indices, c_data));
     return SPMM_OK;
 }

@@ -16,13 +16,18 @@ pytestmark = pytest.mark.gpu
 # plan, every window row through the dense-accumulator kernel, the dense kernel off (cursor kernel
 # with 2^15-column table windows), and the cursor kernel for the symbolic phase with fixed-width
 # numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel; every window
-# row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes).
+# row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes); no window table of
+# B at all (every window row through the launches over B's slab order), with wide windows and dense accumulators,
+# and with narrow windows, the bitmap-rank accumulators and 256-thread workgroups.
 PLANS = {
     "default": {},
     "dense_all": {"SPMM_DENSE_MIN": "1"},
     "dense_off": {"SPMM_DENSE_MIN": "0"},
     "cursor_sym_fixed_windows": {"SPMM_SYM_CFG": "1", "SPMM_ADAPTIVE": "0"},
     "split_rows": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8"},
+    "slab": {"SPMM_SLAB": "1"},
+    "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
+                           "SPMM_SLAB_THREADS": "256"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
 }
 
@@ -271,6 +276,84 @@ def test_product_rows_shared_by_workgroups(ctx):
     ctx.spgemm(_ones_csr(1024, Z["row"], Z["col"]))          # another product's plan in between
     ci, cd = ctx.spgemm_numeric(A, B, c_ip)
     assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+
+
+_PAIR = {}
+
+
+def _same_shape_pair():
+    """Two matrices with the same nrow, ncol and nnz and different structure (the second holds the rows of the first in
+    reverse order), rows in every bin, and the oracle's C = A*A of both."""
+    if not _PAIR:
+        n = 1 << 13
+        row, col = synth.rmat(13, 16, 3)
+        ip, ix, d = orc.csr_from_coo(n, row, col)
+        lens = np.diff(ip)[::-1]
+        ip2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        ix2 = np.concatenate([ix[ip[r]:ip[r + 1]] for r in range(n - 1, -1, -1)]).astype(np.int32)
+        mats = [(ip, ix, d), (ip2, ix2, d.copy())]
+        outs = []
+        for m in mats:
+            o_ip = orc.spgemm_symbolic(n, n, m[0], m[1], m[0], m[1])
+            oi, od, _ = orc.spgemm_numeric(n, m, m, o_ip)
+            outs.append((o_ip, oi, od))
+        prod, _ = orc.row_products(ip, ix, ip)
+        assert prod.max() > 70000 and ((prod > 8192) & (prod < 65536)).any() and (prod <= 64).any()
+        assert not np.array_equal(outs[0][0], outs[1][0])
+        _PAIR.update(n=n, mats=mats, outs=outs)
+    return _PAIR["n"], _PAIR["mats"], _PAIR["outs"]
+
+
+def test_plan_of_another_matrix_is_not_reused_host(ctx):
+    """symbolic(A1), symbolic(A2), numeric(A1), numeric(A2) with equal nrow/ncol/nnz through the host-pointer API (every
+    call uploads into the same device slots): the numeric calls must not bin A1's rows by A2's row products."""
+    n, mats, outs = _same_shape_pair()
+    A = [capi.Csr(n, n, *m) for m in mats]
+    c = [ctx.spgemm_symbolic(a)[0] for a in A]
+    for k in (0, 1):
+        assert np.array_equal(c[k], outs[k][0])
+    for k in (0, 1, 1, 0):
+        ci, cd = ctx.spgemm_numeric(A[k], None, c[k])
+        assert np.array_equal(ci, outs[k][1]) and np.array_equal(cd, outs[k][2])
+    r0, r1 = 5, n // 3
+    ci, cd = ctx.spgemm_numeric(A[1], None, c[1], r0, r1)
+    assert np.array_equal(ci, outs[1][1][c[1][r0]:c[1][r1]]) and np.array_equal(cd, outs[1][2][c[1][r0]:c[1][r1]])
+
+
+def test_plan_of_another_matrix_is_not_reused_dev_refill(ctx):
+    """The same through the device-pointer API with the matrices refilled IN PLACE between the calls: the pointers,
+    shapes and sizes of every call are identical, only the contents differ."""
+    import torch
+    n, mats, outs = _same_shape_pair()
+    dev = torch.device("cuda", 0)
+    nnz = int(mats[0][1].size)
+    t_ip = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    t_ix = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_d = torch.empty(nnz, dtype=torch.float64, device=dev)
+    v = capi.dev_view(n, n, nnz, t_ip, t_ix, t_d)
+
+    def fill(k):
+        ctx.sync()
+        t_ip.copy_(torch.from_numpy(mats[k][0]))
+        t_ix.copy_(torch.from_numpy(mats[k][1]))
+        t_d.copy_(torch.from_numpy(mats[k][2]))
+        torch.cuda.synchronize()
+
+    c_ip = [torch.empty(n + 1, dtype=torch.int64, device=dev) for _ in (0, 1)]
+    for k in (0, 1):
+        fill(k)
+        nnz_c, _ = ctx.spgemm_symbolic_dev(v, v, c_ip[k])
+        ctx.sync()
+        assert nnz_c == int(outs[k][0][-1]) and np.array_equal(c_ip[k].cpu().numpy(), outs[k][0])
+    cap = int(max(o[0][-1] for o in outs))
+    c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
+    c_val = torch.empty(cap, dtype=torch.float64, device=dev)
+    for k in (0, 1, 0):
+        fill(k)
+        ctx.spgemm_numeric_dev(v, v, c_ip[k], 0, n, c_ix, c_val)
+        ctx.sync()
+        m = int(outs[k][0][-1])
+        assert np.array_equal(c_ix[:m].cpu().numpy(), outs[k][1]) and np.array_equal(c_val[:m].cpu().numpy(), outs[k][2])
 
 
 def test_product_sorted_rows_with_many_empty_b_rows(ctx):
