@@ -56,6 +56,9 @@ int spmm_ctx_sync(spmm_ctx* ctx);
 int spmm_ctx_set_stream(spmm_ctx* ctx, void* hip_stream);
 const char* spmm_last_error(void);
 void spmm_free(void* p);
+/* Number of hipMalloc calls ctx has issued for its scratch slots so far (they grow on demand and are kept);
+ * diagnostic, used to check that the allocation-free entry point allocates nothing. */
+long long spmm_ctx_device_allocs(spmm_ctx* ctx);
 /* Milliseconds of GPU time (hipEvent) spent by the kernels of the last host-pointer call on ctx. */
 double spmm_last_kernel_ms(spmm_ctx* ctx);
 
@@ -139,6 +142,15 @@ int spmm_csr_from_coo(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, co
                       const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
 int spmm_csr_from_coo_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
                           const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
+
+/* The same CSR build for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Device pointers as in
+ * spmm_csr_from_coo_dev; every scratch buffer of the kernels comes out of one static device array of 24 MiB that
+ * each GPU the library runs on holds until the process ends, so no hipMalloc/hipFree is issued, whatever was or
+ * was not called on ctx before.  At most 2^20 entries and 2^20 rows (SPMM_E_CAPACITY beyond, nothing is run).
+ * All calls on one GPU share that array: calls that overlap in time on one GPU race. */
+int spmm_csr_from_coo_dev_noalloc(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
+                                  const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
 
 /* ---- CSR build with the loader options the reference lacks (it forces every value to 1.0, keeps
  *      duplicates and ignores symmetry, serial_newblock_clock.cpp:84, 96-98).  val may be NULL (every

@@ -165,6 +165,10 @@ class Context:
         _chk(lib().spmm_spgemm_light_max(self._h, C.c_int32(int(b_ncol)), C.byref(v)))
         return int(v.value)
 
+    def device_allocs(self):
+        lib().spmm_ctx_device_allocs.restype = C.c_longlong
+        return int(lib().spmm_ctx_device_allocs(self._h))
+
     def last_kernel_ms(self):
         return float(lib().spmm_last_kernel_ms(self._h))
 
@@ -206,6 +210,11 @@ class Context:
     def csr_from_coo_dev(self, nrow, ncol, nnz, row, col, indptr, indices, data):
         _chk(lib().spmm_csr_from_coo_dev(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), _p(row), _p(col),
                                          _p(indptr), _p(indices), _p(data)))
+
+    def csr_from_coo_dev_noalloc(self, nrow, ncol, nnz, row, col, indptr, indices, data):
+        """The allocation-free variant (static device scratch, at most 2^20 entries and rows)."""
+        _chk(lib().spmm_csr_from_coo_dev_noalloc(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), _p(row), _p(col),
+                                                 _p(indptr), _p(indices), _p(data)))
 
     # ---- format-generation pipeline (serial_newblock_clock.cpp:221-499) ---------
     def csr_from_coo_opts(self, nrow, ncol, row, col, val=None, symmetric=False, sum_duplicates=False):

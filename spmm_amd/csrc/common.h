@@ -113,7 +113,21 @@ struct spmm_ctx {
     int num_cu = 256;
     void* pinned = nullptr;   // small pinned host buffer for scalar read-backs
     size_t pinned_bytes = 0;
+    // spmm_csr_from_coo_dev_noalloc: scratch requests are served from the static device array of noalloc.hip
+    long long device_allocs = 0;          // hipMalloc calls this context has issued for its scratch slots
+    void* scratch_ptr = nullptr;          // that array's address on this context's device
+    bool arena_on = false;
+    unsigned char* arena_base = nullptr;
+    size_t arena_bytes = 0, arena_off = 0;
+    void* arena_slot[WS_NSLOTS] = {};
+    size_t arena_slot_bytes[WS_NSLOTS] = {};
 };
+
+// noalloc.hip
+constexpr int SPMM_NOALLOC_MAX_NNZ = 1 << 20;
+constexpr int SPMM_NOALLOC_MAX_NROW = 1 << 20;
+constexpr size_t SPMM_NOALLOC_SCRATCH_BYTES = (size_t)24 << 20;   // three sort buffers of 4 MiB, row ends 4 MiB, histograms, sums
+int noalloc_scratch_address(void** out);
 
 int ws_get(spmm_ctx* ctx, int slot, size_t bytes, void** out);
 

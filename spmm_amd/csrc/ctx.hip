@@ -66,6 +66,11 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
         spmm_set_error("hipHostMalloc failed");
         return SPMM_E_HIP;
     }
+    // the static scratch array of the allocation-free entry point, on this device
+    if (noalloc_scratch_address(&c->scratch_ptr) != SPMM_OK) {
+        spmm_ctx_destroy(c);
+        return SPMM_E_HIP;
+    }
     *out = c;
     return SPMM_OK;
 }
@@ -102,12 +107,29 @@ extern "C" int spmm_ctx_set_stream(spmm_ctx* c, void* s) {
     return SPMM_OK;
 }
 
+extern "C" long long spmm_ctx_device_allocs(spmm_ctx* c) { return c ? c->device_allocs : -1; }
+
 extern "C" double spmm_last_kernel_ms(spmm_ctx* c) { return c ? c->last_ms : 0.0; }
 
 // Grow-only scratch slot.  Growing synchronises the stream first so no kernel still reads the
 // old allocation.
 int ws_get(spmm_ctx* c, int slot, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
+    if (c->arena_on) {
+        // allocation-free mode: a slot keeps its piece of the static array for the duration of the call
+        if (c->arena_slot[slot] == nullptr || c->arena_slot_bytes[slot] < bytes) {
+            const size_t want = (bytes + 255) & ~(size_t)255;
+            if (c->arena_off + want > c->arena_bytes) {
+                spmm_set_error("static scratch exhausted: %zu bytes requested at offset %zu of %zu", want, c->arena_off, c->arena_bytes);
+                return SPMM_E_CAPACITY;
+            }
+            c->arena_slot[slot] = c->arena_base + c->arena_off;
+            c->arena_slot_bytes[slot] = want;
+            c->arena_off += want;
+        }
+        *out = c->arena_slot[slot];
+        return SPMM_OK;
+    }
     if (c->slot_bytes[slot] < bytes) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->slot[slot]) HIPCHK(hipFree(c->slot[slot]));
@@ -116,6 +138,7 @@ int ws_get(spmm_ctx* c, int slot, size_t bytes, void** out) {
         size_t want = bytes + bytes / 8 + 256;
         want = (want + 255) & ~(size_t)255;
         HIPCHK(hipMalloc(&c->slot[slot], want));
+        c->device_allocs++;
         if (slot == WS_STAMPS) HIPCHK(hipMemsetAsync(c->slot[slot], 0, want, c->stream));
         c->slot_bytes[slot] = want;
     }
