@@ -32,9 +32,11 @@ from spmm_amd import capi, shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 
-def rmat_torch(scale, edge_factor, seed, device):
+def rmat_torch(scale, edge_factor, seed, device, row_lo=None, row_hi=None):
     """Graph500 R-MAT (a,b,c,d = .57,.19,.19,.05), level l decides bit l, no scrambling; dedup and
-    (col,row) order like a SuiteSparse file.  Philox stream of torch, seeded."""
+    (col,row) order like a SuiteSparse file.  Philox stream of torch, seeded.  With row_lo/row_hi only the
+    entries of rows [row_lo, row_hi) are kept, BEFORE the dedup sort: every rank draws the same stream and
+    sorts only its own slice of it (duplicates of an entry share its row, so they meet in one slice)."""
     a, b, c = 0.57, 0.19, 0.19
     n, m = 1 << scale, edge_factor << scale
     g = torch.Generator(device=device)
@@ -46,8 +48,11 @@ def rmat_torch(scale, edge_factor, seed, device):
         row |= (u >= a + b).to(torch.int64) << level
         col |= (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64) << level
         del u
-    key = torch.unique(col * n + row)
+    key = col * n + row
+    if row_lo is not None:
+        key = key[(row >= row_lo) & (row < row_hi)]
     del row, col
+    key = torch.unique(key)
     return (key & (n - 1)).to(torch.int32), (key >> scale).to(torch.int32)
 
 
@@ -57,7 +62,9 @@ def build_csr(ctx, n_rows, ncol, row, col):
     indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
     indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
     data = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()       # row/col come from torch kernels; the library reads them through its own runtime handle
     ctx.csr_from_coo_dev(n_rows, ncol, nnz, row, col, indptr, indices, data)
+    ctx.sync()
     return indptr, indices[:nnz], data[:nnz]
 
 
@@ -70,7 +77,7 @@ def main():
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--cbuf-gib", type=float, default=96.0, help="output buffer (indices+values) per GPU")
-    ap.add_argument("--cpu-products", type=float, default=1.5e9, help="size of the CPU baseline sample")
+    ap.add_argument("--cpu-products", type=float, default=2.5e9, help="size of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -120,15 +127,16 @@ def main():
     # ---- set-up (untimed): graph, CSR, B on every GPU ------------------------
     t0 = time.time()
     n = 1 << args.scale
-    row, col = rmat_torch(args.scale, args.edge_factor, args.seed, dev)
-    nnz = int(row.numel())
     b_allgather_ms = 0.0
     if world == 1:
+        row, col = rmat_torch(args.scale, args.edge_factor, args.seed, dev)
+        nnz = int(row.numel())
         indptr, indices, data = build_csr(ctx, n, n, row, col)
     else:
         lo, hi = shard.even_row_slice(n, rank, world)
-        m = (row >= lo) & (row < hi)
-        ip_l, ix_l, _ = build_csr(ctx, hi - lo, n, (row[m] - lo).contiguous(), col[m].contiguous())
+        row, col = rmat_torch(args.scale, args.edge_factor, args.seed, dev, lo, hi)    # this rank's rows only
+        ip_l, ix_l, _ = build_csr(ctx, hi - lo, n, (row - lo).contiguous(), col)
+        ctx.sync()
         torch.cuda.synchronize()
         dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -137,9 +145,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         b_allgather_ms = e0.elapsed_time(e1)
+        nnz = int(indices.numel())
         data = torch.ones(nnz, dtype=torch.float64, device=dev)
-        del m
-        assert int(indptr[-1]) == nnz == indices.numel()
+        assert int(indptr[-1]) == nnz
     del row, col
     torch.cuda.synchronize()
 
@@ -147,7 +155,6 @@ def main():
     prod = torch.empty(n, dtype=torch.int64, device=dev)
     P_total = ctx.row_products_dev(vB, vB, prod)
     # rows of A per rank: equal shares of the intermediate products, weighted by the kernel class of the row
-    cum = torch.cumsum(prod, 0)
     _, esc_max = capi.bin_limits()
     _, _, dense_min_products = ctx.plan_info(n)
     bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min_products, max(ctx.light_max(n), esc_max),
@@ -317,32 +324,64 @@ def main():
                          frac_of_hbm_peak=round(b_sym / (t_sym * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if t_sym > 0 else None),
         "bins_ms_per_step": round(ph["bins"][0] / args.steps, 3)}
 
-    # ---- CPU baseline: the oracle's serial Gustavson on the first rows of the same matrix -----
-    cpu = None
+    # ---- CPU baseline: the oracle's Gustavson on a sample of rows of the same matrix, spread over the product
+    # distribution (every 1/S-th point of the cumulative products, so heavy and light rows weigh as in the whole job),
+    # on one core and row-parallel on the host cores of this box's share; the pre-processing pipeline beside it ----
+    cpu, pre = None, None
     if not args.no_cpu and world == 1:
         from oracle import oracle as orc
-        target = args.cpu_products
-        cum_h = cum[:min(n, 1 << 22)].cpu().numpy()
-        R = int(np.searchsorted(cum_h, target)) + 1
-        R = max(1, min(R, rows_l if world > 1 else n))
+        threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1, 16))
+        prod_h = prod.cpu().numpy()
+        order = np.argsort(prod_h, kind="stable")
+        cum_sorted = np.cumsum(prod_h[order])
+        mean_hit = float((prod_h.astype(np.float64) ** 2).sum() / max(cum_sorted[-1], 1))   # products of the row under a random product
+        S = max(8, int(args.cpu_products / max(mean_hit, 1.0)))
+        picks = np.unique(np.searchsorted(cum_sorted, (np.arange(S) + 0.5) * (cum_sorted[-1] / S)))
+        rows_s = np.sort(order[picks]).astype(np.int32)
         ip_h, ix_h = indptr.cpu().numpy(), indices.cpu().numpy()
         d_h = np.ones(nnz, np.float64)
+        M = (ip_h, ix_h, d_h)
         tc = time.perf_counter()
-        o_ip = orc.spgemm_symbolic(R, n, ip_h[:R + 1], ix_h, ip_h, ix_h)
-        oi, od, p_s = orc.spgemm_numeric(n, (ip_h[:R + 1], ix_h, d_h), (ip_h, ix_h, d_h), o_ip)
-        tcpu = time.perf_counter() - tc
-        cpu = dict(value=round(2.0 * p_s / tcpu / 1e9, 4), unit="GFLOP/s", cores=1, kind="port",
-                   sample=f"rows 0..{R - 1} of the same matrix ({p_s} products, symbolic+numeric, {tcpu:.1f} s)",
+        cnt1, vs1, p_s = orc.spgemm_rows(n, M, M, rows_s, 1)
+        t1c = time.perf_counter() - tc
+        tc = time.perf_counter()
+        cntN, vsN, p_n = orc.spgemm_rows(n, M, M, rows_s, threads)
+        tNc = time.perf_counter() - tc
+        assert p_s == p_n == int(prod_h[rows_s].sum()) and vs1 == float(p_s) and np.array_equal(cnt1, cntN)
+        cpu = dict(value=round(2.0 * p_s / t1c / 1e9, 4), unit="GFLOP/s", cores=1, kind="port",
+                   sample=f"{rows_s.size} rows of the same matrix at equal steps of the cumulative product count "
+                          f"({p_s} products, {int(cnt1.sum())} entries of C, one pass that counts and sums, {t1c:.1f} s)",
+                   all_cores=dict(value=round(2.0 * p_s / tNc / 1e9, 4), cores=threads, seconds=round(tNc, 2)),
                    host_cpus=os.cpu_count())
-        # the same rows from the GPU must match the oracle exactly
-        if r_lo == 0 and R <= rows_l and int(o_ip[-1]) <= cap:
-            assert np.array_equal(state["c_ip_h"][:R + 1], o_ip), "GPU row pointers differ from the oracle"
-            ctx.spgemm_numeric_dev(vA, vB, c_ip, 0, R, c_ix, c_val)
-            torch.cuda.synchronize()
-            k = int(o_ip[-1])
-            assert np.array_equal(c_ix[:k].cpu().numpy(), oi), "GPU column ids differ from the oracle"
-            assert np.array_equal(c_val[:k].cpu().numpy(), od), "GPU values differ from the oracle"
+        # the same rows from the GPU: row counts bit for bit; the heaviest sampled row entry for entry
+        if r_lo == 0 and rows_l == n:
+            assert np.array_equal(np.diff(state["c_ip_h"])[rows_s], cnt1), "GPU row counts differ from the oracle"
+            rh = int(rows_s[np.argmax(prod_h[rows_s])])
+            o_ip1 = np.array([0, int(cnt1[np.argmax(prod_h[rows_s])])], np.int64)
+            if int(o_ip1[1]) <= cap:
+                sub = (np.array([0, ip_h[rh + 1] - ip_h[rh]], np.int32), ix_h[ip_h[rh]:ip_h[rh + 1]], d_h[:ip_h[rh + 1] - ip_h[rh]])
+                oi, od, _ = orc.spgemm_numeric(n, sub, M, o_ip1)
+                ctx.spgemm_numeric_dev(vA, vB, c_ip, rh, rh + 1, c_ix, c_val)
+                sync_all()
+                k = int(o_ip1[1])
+                assert np.array_equal(c_ix[:k].cpu().numpy(), oi) and np.array_equal(c_val[:k].cpu().numpy(), od), \
+                    "the heaviest sampled row differs from the oracle"
             cpu["gpu_rows_match_oracle"] = True
+        # pre-processing (the reference's own metric: the stages of gen_trace_formats, serial_newblock_clock.cpp:565)
+        A_h = capi.Csr(n, n, ip_h, ix_h, d_h)
+        ctx.trace_formats(A_h)                                    # warm-up: scratch allocations
+        tw = time.perf_counter()
+        g = ctx.trace_formats(A_h)
+        wall_ms = (time.perf_counter() - tw) * 1e3
+        gpu_ms = ctx.last_kernel_ms()
+        tc = time.perf_counter()
+        o = orc.trace_formats(n, ip_h, ix_h, d_h, sort_mode=1)
+        cpu_ms = (time.perf_counter() - tc) * 1e3
+        same = all(np.array_equal(g[k], o[k]) for k in ("seq_bitmap", "bsize_list", "seq_offset", "seq_input", "rseq"))
+        pre = dict(gpu_ms=round(gpu_ms, 2), gpu_wall_ms_host_arrays_in_and_out=round(wall_ms, 1), cpu_oracle_ms=round(cpu_ms, 1), cores=1,
+                   blocks=int(g["bnum"]), gpu_equals_oracle=bool(same),
+                   what="spmm_trace_formats on the same matrix: bitmap reorder + blocks + panels + pack + renumber + write-back sequence")
+        del g, o, A_h
 
     out = dict(metric="spgemm_gflops", value=round(gflops, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
                warmup=max(args.warmup, 1), ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",
@@ -352,7 +391,7 @@ def main():
                            step="symbolic+numeric", c_row_blocks_per_step=state["blocks"], rank0_rows=rows_l,
                            b_allgather_ms=round(b_allgather_ms, 3), setup_s=round(setup_s, 1)),
                phases_ms_per_step={k: round(v[0] / args.steps, 3) for k, v in ph.items()},
-               phase_totals_rank0=phase_totals, roofline=roofline, cpu_baseline=cpu)
+               phase_totals_rank0=phase_totals, roofline=roofline, cpu_baseline=cpu, preprocess=pre)
     if stamps:
         out["stamps"] = stamps
     print(json.dumps(out), flush=True)

@@ -319,6 +319,23 @@ def spgemm_numeric(ncolB, a, b, c_indptr, row_beg=0, row_end=None):
     return ci, cd, int(prods)
 
 
+def spgemm_rows(ncolB, a, b, rows, threads=1):
+    """Gustavson over a list of rows with `threads` OpenMP threads (the CPU baseline of the benchmark).  Returns
+    (entries of C per listed row, sum of all values, intermediate products)."""
+    a_ip, a_ix = _i32(a[0]), _i32(a[1])
+    b_ip, b_ix = _i32(b[0]), _i32(b[1])
+    a_d = np.ascontiguousarray(a[2], F64)
+    b_d = np.ascontiguousarray(b[2], F64)
+    rows = _i32(rows)
+    counts = np.zeros(rows.size, I64)
+    vsum = C.c_double()
+    f = lib().orc_spgemm_rows_omp
+    f.restype = C.c_int64
+    prods = f(C.c_int32(rows.size), _p(rows), C.c_int32(ncolB), _p(a_ip), _p(a_ix), _p(a_d), _p(b_ip), _p(b_ix), _p(b_d),
+              C.c_int32(int(threads)), _p(counts), C.byref(vsum))
+    return counts, float(vsum.value), int(prods)
+
+
 def spgemm(ncolB, a, b):
     c_indptr = spgemm_symbolic(len(a[0]) - 1, ncolB, a[0], a[1], b[0], b[1])
     ci, cd, _ = spgemm_numeric(ncolB, a, b, c_indptr)

@@ -428,6 +428,47 @@ int64_t orc_spgemm_numeric(int32_t row_beg, int32_t row_end, int32_t ncolB,
     return products;
 }
 
+// The same Gustavson product over a LIST of rows, row-parallel over `threads` OpenMP threads (1 = serial): the CPU
+// baseline timed beside the GPU.  Every thread keeps its own dense accumulator; a row's sorted column ids and sums
+// are produced and folded into counts[t] (entries of C of rows[t]) and *value_sum (sum of all values), not stored.
+// NOT IN THE REFERENCE, like the product itself.  Returns the intermediate products of the listed rows.
+int64_t orc_spgemm_rows_omp(int32_t nlist, const int32_t* rows, int32_t ncolB, const int32_t* a_indptr,
+                            const int32_t* a_indices, const double* a_data, const int32_t* b_indptr,
+                            const int32_t* b_indices, const double* b_data, int32_t threads, int64_t* counts,
+                            double* value_sum) {
+    int64_t products = 0;
+    double vsum = 0.0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads) reduction(+ : products, vsum)
+    {
+        std::vector<int32_t> mark((size_t)ncolB, -1);
+        std::vector<double> acc((size_t)ncolB, 0.0);
+        std::vector<int32_t> cols;
+#pragma omp for schedule(dynamic, 1)
+        for (int32_t t = 0; t < nlist; t++) {
+            const int32_t i = rows[t];
+            cols.clear();
+            for (int32_t p = a_indptr[i]; p < a_indptr[i + 1]; p++) {
+                const int32_t k = a_indices[p];
+                const double av = a_data[p];
+                for (int32_t q = b_indptr[k]; q < b_indptr[k + 1]; q++) {
+                    const int32_t c = b_indices[q];
+                    if (mark[c] != t) { mark[c] = t; acc[c] = 0.0; cols.push_back(c); }
+                    acc[c] += av * b_data[q];
+                    products++;
+                }
+            }
+            std::sort(cols.begin(), cols.end());
+            double s = 0.0;
+            for (size_t u = 0; u < cols.size(); u++) s += acc[cols[u]];
+            vsum += s;
+            counts[t] = (int64_t)cols.size();
+        }
+    }
+    if (value_sum) *value_sum = vsum;
+    return products;
+}
+
 // Intermediate products per row: prod[i] = sum over A entries (i,k) of len_B(k).
 int64_t orc_row_products(int32_t nrow, const int32_t* a_indptr, const int32_t* a_indices,
                          const int32_t* b_indptr, int64_t* prod) {

@@ -15,6 +15,11 @@
 // With SPMM_HARNESS_TRACE=<dir> every array of the pipeline, the per-block formats included (which
 // the reference computes and drops, :221 by-value parameters, :363), is written to
 // <dir>/<name>/<array>.npy (NumPy format 1.0, little endian, C order).
+// With SPMM_HARNESS_CACHE=1 the entries read from <name>.mtx are also written to <name>.mtx.bin (sizes, a
+// fingerprint of the text, then the zero-based row and column ids), and a later run whose text has the same
+// fingerprint (size, first and last 64 KiB) reads that file instead of the text: the reference reads the text
+// with `fin >>` on every run (:47-104), which for a graph of 2.6e8 entries is minutes.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +73,71 @@ bool write_npy(const std::string& path, const T* a, size_t n, const char* descr)
     return std::fclose(f) == 0 && ok;
 }
 
+// ---- binary side-cache of the entries of a .mtx file -----------------------------------------------------
+struct CacheHeader {
+    char magic[8];            // "SPMMBIN1"
+    int32_t nrow, ncol;
+    int64_t nnz;
+    uint64_t text_bytes, text_fingerprint;
+};
+
+// FNV-1a-64 over the size of the file and its first and last 64 KiB: what is compared instead of re-reading the text
+bool text_fingerprint(const std::string& path, uint64_t* bytes, uint64_t* fp) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    if (sz < 0) { std::fclose(f); return false; }
+    const size_t piece = 64 * 1024;
+    std::vector<unsigned char> buf(2 * piece);
+    size_t got = 0;
+    std::fseek(f, 0, SEEK_SET);
+    got += std::fread(buf.data(), 1, std::min<size_t>(piece, (size_t)sz), f);
+    if ((size_t)sz > piece) {
+        const size_t tail = std::min<size_t>(piece, (size_t)sz - piece);
+        std::fseek(f, (long)((size_t)sz - tail), SEEK_SET);
+        got += std::fread(buf.data() + got, 1, tail, f);
+    }
+    std::fclose(f);
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 8; i++) h = (h ^ (((uint64_t)sz >> (8 * i)) & 255u)) * 1099511628211ull;
+    for (size_t i = 0; i < got; i++) h = (h ^ buf[i]) * 1099511628211ull;
+    *bytes = (uint64_t)sz;
+    *fp = h;
+    return true;
+}
+
+bool load_cache(const std::string& bin, uint64_t bytes, uint64_t fp, int* nrow, int* ncol, std::vector<int>& row, std::vector<int>& col) {
+    FILE* f = std::fopen(bin.c_str(), "rb");
+    if (!f) return false;
+    CacheHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "SPMMBIN1", 8) == 0 && h.text_bytes == bytes &&
+              h.text_fingerprint == fp && h.nnz >= 0 && h.nnz < (1ll << 31) && h.nrow >= 0 && h.ncol >= 0;
+    if (ok) {
+        row.resize((size_t)h.nnz);
+        col.resize((size_t)h.nnz);
+        ok = (h.nnz == 0 || (std::fread(row.data(), 4, (size_t)h.nnz, f) == (size_t)h.nnz && std::fread(col.data(), 4, (size_t)h.nnz, f) == (size_t)h.nnz));
+        *nrow = h.nrow;
+        *ncol = h.ncol;
+    }
+    std::fclose(f);
+    return ok;
+}
+
+void save_cache(const std::string& bin, uint64_t bytes, uint64_t fp, int nrow, int ncol, const std::vector<int>& row, const std::vector<int>& col) {
+    const std::string tmp = bin + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;                           // a read-only input directory: run without the cache
+    CacheHeader h;
+    std::memcpy(h.magic, "SPMMBIN1", 8);
+    h.nrow = nrow; h.ncol = ncol; h.nnz = (int64_t)row.size(); h.text_bytes = bytes; h.text_fingerprint = fp;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    ok = ok && (row.empty() || (std::fwrite(row.data(), 4, row.size(), f) == row.size() && std::fwrite(col.data(), 4, col.size(), f) == col.size()));
+    ok = (std::fclose(f) == 0) && ok;
+    if (ok) std::rename(tmp.c_str(), bin.c_str());
+    else std::remove(tmp.c_str());
+}
+
 #define CK(call)                                                              \
     do {                                                                      \
         int rc_ = (call);                                                     \
@@ -82,7 +152,13 @@ bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, st
     int nrow = 0, ncol = 0;
     std::vector<int> row, col;
     auto t0 = std::chrono::high_resolution_clock::now();
-    {
+    const char* cache_env = std::getenv("SPMM_HARNESS_CACHE");
+    const bool use_cache = cache_env && std::atoi(cache_env) != 0;
+    uint64_t text_bytes = 0, text_fp = 0;
+    bool from_cache = false;
+    if (use_cache && text_fingerprint(path, &text_bytes, &text_fp))
+        from_cache = load_cache(path + ".bin", text_bytes, text_fp, &nrow, &ncol, row, col);
+    if (!from_cache) {
         // MatrixMarket text -> entries (serial_newblock_clock.cpp:47-104): header on the host,
         // the entries on the GPU
         std::vector<char> text;
@@ -97,6 +173,7 @@ bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, st
         row.resize((size_t)nz);
         col.resize((size_t)nz);
         CK(spmm_mtx_entries(ctx, text.data(), bytes, data_offset, per, nz, row.data(), col.data()));
+        if (use_cache && text_bytes == bytes) save_cache(path + ".bin", text_bytes, text_fp, nrow, ncol, row, col);
     }
     auto t1 = std::chrono::high_resolution_clock::now();
     const int nnz = (int)row.size();
@@ -190,11 +267,11 @@ bool process(spmm_ctx* ctx, const std::string& mname, std::ofstream& outfile, st
         }
         char line[1024];
         std::snprintf(line, sizeof line,
-                      "{\"name\": \"%s\", \"rows\": %d, \"nnz\": %d, \"read_ms\": %.3f, \"csr_build_gpu_ms\": %.3f, "
+                      "{\"name\": \"%s\", \"rows\": %d, \"nnz\": %d, \"entries_from\": \"%s\", \"read_ms\": %.3f, \"csr_build_gpu_ms\": %.3f, "
                       "\"preprocess_gpu_ms\": %.3f, \"preprocess_wall_ms\": %.3f, \"blocks\": %d, \"products\": %lld, "
                       "\"nnz_c\": %lld, \"symbolic_gpu_ms\": %.3f, \"numeric_gpu_ms\": %.3f, \"gflops_numeric\": %.2f, "
                       "\"c_indices_fnv1a64\": \"%016llx\", \"c_value_sum\": %.17g}",
-                      mname.c_str(), nrow, nnz, ms_read, ms_csr, ms_gpu, ms_wall, tr.bnum, (long long)products,
+                      mname.c_str(), nrow, nnz, from_cache ? "cache" : "text", ms_read, ms_csr, ms_gpu, ms_wall, tr.bnum, (long long)products,
                       (long long)nnz_c, ms_sym, ms_num, ms_num > 0 ? 2.0 * products / (ms_num * 1e-3) / 1e9 : 0.0,
                       (unsigned long long)hash, sum);
         *spg << line << std::endl;

@@ -23,6 +23,8 @@ def allgather_csr_slices(indptr_local, indices_local, n, rank, world, dist):
     cnts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(cnts, cnt)
     cnts_h = [int(x) for x in cnts.cpu().tolist()]
+    if sum(cnts_h) >= 2 ** 31 - 64:
+        raise ValueError(f"the gathered matrix would hold {sum(cnts_h)} entries: row pointers are int32 (csr.h:10-13)")
     mx = max(max(cnts_h), 1)
     pad = torch.zeros(mx, dtype=torch.int32, device=dev)
     pad[:indices_local.numel()] = indices_local

@@ -60,6 +60,34 @@ def web_like(n=916428, m=5105039, seed=3):
     return _finish(row, col, n)
 
 
+def stanford_like(n=281903, m=2312497, seed=8):
+    """A graph of the size and rough shape of SNAP web-Stanford (281 903 pages, 2.3 M links, out-degrees up to 255,
+    in-degrees up to tens of thousands): ordinary pages with geometric out-degrees whose targets are a Pareto-ranked
+    popular head (four in ten) or uniform, plus 3 000 navigation pages in 60 sites of 50 that link to every other
+    navigation page of their site and to 100-200 pages more, so that rows of A*A reach tens of thousands of products
+    (the window bins), as the link-dense cores of real web graphs make them."""
+    rng = np.random.default_rng(seed)
+    nav = rng.choice(n, 3000, replace=False).reshape(60, 50)
+    rows, cols = [], []
+    for site in nav:
+        rows.append(np.repeat(site, 50))
+        cols.append(np.tile(site, 50))
+        extra = rng.integers(100, 200, 50)
+        rows.append(np.repeat(site, extra))
+        cols.append(rng.integers(0, n, int(extra.sum())))
+    used = sum(r.size for r in rows)
+    deg = rng.geometric(0.14, n)
+    deg = (deg * ((m - used) / deg.sum())).astype(np.int64) + 1
+    row = np.repeat(np.arange(n), deg)[:m - used]
+    pop = (rng.pareto(1.0, row.size) * 20).astype(np.int64) % n
+    navt = nav.reshape(-1)[rng.integers(0, 3000, row.size)]
+    u = rng.random(row.size)
+    col = np.where(u < 0.35, pop, np.where(u < 0.45, navt, rng.integers(0, n, row.size)))
+    rows.append(row)
+    cols.append(col)
+    return _finish(np.concatenate(rows), np.concatenate(cols), n)
+
+
 def askubuntu_like(n=159316, m=964437, seed=5):
     """A graph of the size and rough shape of SNAP sx-askubuntu (159 316 users, 964 437 timed interactions, about
     0.6 M distinct pairs): both ends of an interaction drawn from heavy-tailed activity ranks (user id = n*u^3 for the

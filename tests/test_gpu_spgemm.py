@@ -136,7 +136,8 @@ def _snap_like(name):
     """(A, c_indptr, c_indices, c_data) of the oracle for a graph of the size and rough shape of a SNAP input the
     benchmark names (the files are not available offline); computed once for all plans."""
     if name not in _SNAP_LIKE:
-        n, gen = {"web-Google": (916428, synth.web_like), "sx-askubuntu": (159316, synth.askubuntu_like)}[name]
+        n, gen = {"web-Google": (916428, synth.web_like), "sx-askubuntu": (159316, synth.askubuntu_like),
+                  "web-Stanford": (281903, synth.stanford_like)}[name]
         row, col = gen()
         ip, ix, d = orc.csr_from_coo(n, row, col)
         o_ip = orc.spgemm_symbolic(n, n, ip, ix, ip, ix)
@@ -145,9 +146,10 @@ def _snap_like(name):
     return _SNAP_LIKE[name]
 
 
-@pytest.mark.parametrize("name", ["web-Google", "sx-askubuntu"])
+@pytest.mark.parametrize("name", ["web-Stanford", "web-Google", "sx-askubuntu"])
 def test_product_snap_sized_graphs(ctx, name):
-    """Whole C of a web-Google-sized graph (5.1 M entries, every row in the smallest sorted bin) and of an
+    """Whole C of a web-Stanford-sized graph (2.3 M entries, a popular head that puts rows into the window bins), of a
+    web-Google-sized graph (5.1 M entries, every row in the smallest sorted bin) and of an
     sx-askubuntu-sized one (0.9 M entries, 5.4e8 products, skewed rows in every bin) against the oracle."""
     A, o_ip, oi, od = _snap_like(name)
     c_ip, nnz_c, _ = ctx.spgemm_symbolic(A)
@@ -416,3 +418,31 @@ def test_product_empty(ctx):
     assert c_ip.tolist() == [0] * 5 and nnz_c == 0 and prods == 0
     ci, cd = ctx.spgemm_numeric(A, None, c_ip)
     assert ci.size == 0
+
+
+def test_product_of_a_row_shard_view(ctx):
+    """The view of A that the multi-GPU benchmark hands every rank: row pointers starting at the shard's first row
+    (indptr[r_lo:], first value not 0), the indices and data of the WHOLE matrix, nnz of the whole matrix.  Symbolic
+    and numeric over such views (one of them with no rows at all) must give the matching rows of the whole product."""
+    import torch
+    n, mats, outs = _same_shape_pair()
+    ip, ix, d = mats[0]
+    o_ip, oi, od = outs[0]
+    dev = torch.device("cuda", 0)
+    t_ip, t_ix, t_d = (torch.from_numpy(x).to(dev) for x in (ip, ix, d))
+    nnz = int(ix.size)
+    vB = capi.dev_view(n, n, nnz, t_ip, t_ix, t_d)
+    torch.cuda.synchronize()
+    for r_lo, r_hi in [(0, 3), (3, 3), (3, 2000), (2000, n)]:
+        rows = r_hi - r_lo
+        vA = capi.dev_view(rows, n, nnz, t_ip[r_lo:], t_ix, t_d)
+        c_ip = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+        nnz_c, prods = ctx.spgemm_symbolic_dev(vA, vB, c_ip)
+        ctx.sync()
+        assert np.array_equal(c_ip.cpu().numpy(), o_ip[r_lo:r_hi + 1] - o_ip[r_lo]) and nnz_c == int(o_ip[r_hi] - o_ip[r_lo])
+        c_ix = torch.empty(max(nnz_c, 1), dtype=torch.int32, device=dev)
+        c_val = torch.empty(max(nnz_c, 1), dtype=torch.float64, device=dev)
+        ctx.spgemm_numeric_dev(vA, vB, c_ip, 0, rows, c_ix, c_val)
+        ctx.sync()
+        assert np.array_equal(c_ix[:nnz_c].cpu().numpy(), oi[o_ip[r_lo]:o_ip[r_hi]])
+        assert np.array_equal(c_val[:nnz_c].cpu().numpy(), od[o_ip[r_lo]:o_ip[r_hi]])

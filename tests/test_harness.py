@@ -71,3 +71,35 @@ def test_harness_end_to_end(tmp_path):
                 continue
             got = np.load(tmp_path / "trace" / name / f"{key}.npy")
             assert got.dtype == want.dtype and np.array_equal(got, want), key
+
+
+@pytest.mark.gpu
+def test_harness_binary_side_cache_and_a_web_sized_graph(tmp_path):
+    """SPMM_HARNESS_CACHE=1: the first run parses the text and leaves <name>.mtx.bin, the second reads the entries from
+    it (no text parse) and reports the same product digests; a changed text invalidates the cache.  The graph is the
+    web-Stanford-sized stand-in (281 903 rows, 2.3 M entries), checked against the oracle as well."""
+    n = 281903
+    row, col = synth.stanford_like()
+    _workdir(tmp_path, {"stanford": (n, row, col)})
+    env = dict(os.environ, SPMM_HARNESS_SPGEMM="1", SPMM_HARNESS_CACHE="1")
+
+    def run():
+        r = subprocess.run([SERIAL], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        return json.loads((tmp_path / "result_spgemm.txt").read_text().splitlines()[0])
+
+    first = run()
+    bin_path = tmp_path / "mat" / "mtx" / "stanford" / "stanford.mtx.bin"
+    assert first["entries_from"] == "text" and bin_path.exists()
+    second = run()
+    assert second["entries_from"] == "cache"
+    for k in ("rows", "nnz", "blocks", "products", "nnz_c", "c_indices_fnv1a64", "c_value_sum"):
+        assert first[k] == second[k], k
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    c_ip, c_ix, c_d = orc.spgemm(n, (ip, ix, d), (ip, ix, d))
+    assert second["nnz"] == ix.size and second["nnz_c"] == int(c_ip[-1]) and second["c_indices_fnv1a64"] == f"{orc.fnv(c_ix):016x}"
+    assert second["c_value_sum"] == float(c_d.sum()) and second["blocks"] == orc.trace_formats(n, ip, ix, d)["bnum"]
+    # another text under the same name: one entry fewer
+    synth.write_mtx(str(tmp_path / "mat" / "mtx" / "stanford" / "stanford.mtx"), n, row[:-1], col[:-1])
+    third = run()
+    assert third["entries_from"] == "text" and third["nnz"] == ix.size - 1

@@ -21,7 +21,8 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    for name, n, gen in (("web-Google-like", 916428, synth.web_like), ("sx-askubuntu-like", 159316, synth.askubuntu_like)):
+    for name, n, gen in (("web-Stanford-like", 281903, synth.stanford_like), ("web-Google-like", 916428, synth.web_like),
+                         ("sx-askubuntu-like", 159316, synth.askubuntu_like)):
         row, col = gen()
         ip, ix, d = orc.csr_from_coo(n, row, col)
         nnz = int(ix.size)
