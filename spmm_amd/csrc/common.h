@@ -43,7 +43,7 @@ void spmm_set_error(const char* fmt, ...);
 enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
     WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_ESC_M, WS_LIST_GIANT, WS_GSLOT, WS_WCNT, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
-    WS_WINPTR, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
+    WS_WINPTR, WS_B12, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_P0, WS_P1, WS_P2, WS_P3, WS_P4, WS_P5, WS_P6, WS_P7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     // slab order of B for the window launches over the heaviest rows: kept between symbolic and numeric (PERM .. SLOTROW), scratch of the build (T0 .. T5)
     WS_SL_PERM, WS_SL_COL, WS_SL_VAL, WS_SL_PIECE, WS_SL_PFIRST, WS_SL_PFIRSTW, WS_SL_CUR, WS_SL_NW, WS_SL_CNT, WS_SL_WB, WS_SL_LUT, WS_SL_SLOTROW, WS_SL_EBASE, WS_SL_WROW, WS_SL_ITEMS, WS_SL_ITEMA, WS_SL_RCOUNT, WS_SL_TICKET, WS_SL_AROW0, WS_SL_OBASE, WS_SL_CNTR,

@@ -48,6 +48,30 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// B as 12-byte records {column id, value}: a short piece of a row of B (most pieces a window kernel reads hold a few
+// products) then lies in one cache line instead of one line of column ids and one of values.  Packed by every
+// numeric call (k_pack_b12) from the caller's arrays.
+struct colval { int col; double val; };
+__device__ __forceinline__ colval ld_b12(const uint32_t* __restrict__ b12, int pos) {
+    const uint3 r = *reinterpret_cast<const uint3*>(b12 + 3ull * (unsigned)pos);
+    colval cv;
+    cv.col = (int)r.x;
+    cv.val = __hiloint2double((int)r.z, (int)r.y);
+    return cv;
+}
+__global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int64_t nnz,
+                                                  uint32_t* __restrict__ b12) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nnz; p += stride) {
+        const double v = b_val[p];
+        uint3 r;
+        r.x = (uint32_t)b_ix[p];
+        r.y = (uint32_t)__double2loint(v);
+        r.z = (uint32_t)__double2hiint(v);
+        *reinterpret_cast<uint3*>(b12 + 3 * p) = r;
+    }
+}
+
 enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_N = 14 };
 
 // ---------------------------------------------------------------------------
@@ -860,7 +884,7 @@ __device__ __forceinline__ unsigned long long win_clock() {
 template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP>
 __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                                 const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
+                                                 const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12,
                                                  const int32_t* __restrict__ winptr, int nbase, int shift,
                                                  const int64_t* __restrict__ prod, int32_t* __restrict__ rowcnt,
                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
@@ -1087,8 +1111,9 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                 double bv[U];
 #pragma unroll
                 for (int j = 0; j < U; j++) {
-                    cc[j] = b_ix[pos[j]];
-                    bv[j] = b_val[pos[j]];
+                    const colval cv = ld_b12(b12, pos[j]);
+                    cc[j] = cv.col;
+                    bv[j] = cv.val;
                 }
 #pragma unroll
                 for (int j = 0; j < U; j++) {
@@ -1267,8 +1292,9 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                         double bv[UG];
 #pragma unroll
                         for (int j = 0; j < UG; j++) {
-                            c[j] = (ok & (1u << j)) ? b_ix[pos[j]] : 0;
-                            bv[j] = (ok & (1u << j)) ? b_val[pos[j]] : 0.0;
+                            const colval cv = ld_b12(b12, (ok & (1u << j)) ? pos[j] : 0);
+                            c[j] = (ok & (1u << j)) ? cv.col : 0;
+                            bv[j] = (ok & (1u << j)) ? cv.val : 0.0;
                         }
 #pragma unroll
                         for (int j = 0; j < UG; j++) {   // rank look-ups before any atomic (see above)
@@ -1393,7 +1419,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // have been issued (or at the end when there is no batch): work of the caller that consumes
 // earlier loads goes there, so that those and the batch's loads are in flight together.
 template <bool WITH_VAL, typename F, typename G>
-__device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int s,
+__device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12, int s,
                                                 int rem, double a, int lane, uint8_t* wmap, F&& act, G&& between) {
     uint32_t* wmap4 = (uint32_t*)wmap;
     rem = rem > 0 ? rem : 0;
@@ -1450,8 +1476,14 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
             const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last product
             sq[j] = (int)wmap[qc - b0] - 1;
             const int pos = __shfl(so, sq[j], 64) + qc;
-            bq[j] = WITH_VAL ? b_val[pos] : 0.0;              // value first: the wait for the column covers it
-            cq[j] = b_ix[pos];
+            if (WITH_VAL) {
+                const colval cv = ld_b12(b12, pos);
+                bq[j] = cv.val;
+                cq[j] = cv.col;
+            } else {
+                bq[j] = 0.0;
+                cq[j] = b_ix[pos];
+            }
         }
         if (b0 == 0) between();
         // the entry's value of A is fetched while the loads are in flight (holding the source lane costs
@@ -1484,7 +1516,7 @@ __device__ __forceinline__ void store_b128(double* p, double a, double b) {
 template <int THREADS, bool STAMP>
 __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                    const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                                   const int32_t* __restrict__ b_ix, const double* __restrict__ b_val,
+                                                   const uint32_t* __restrict__ b12,
                                                    const int32_t* __restrict__ winptr, int nbase, int shift,
                                                    const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                    int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg_arg,
@@ -1563,8 +1595,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             // them and does not drain every outstanding load at the next reuse of a register
             const int len = t_nxt - t_cur;
             const int q0 = pi < len ? t_cur + pi : 0, q1 = pi + LA < len ? t_cur + pi + LA : 0;
-            pb0 = b_val[q0]; pb1 = b_val[q1];
-            pc0 = b_ix[q0]; pc1 = b_ix[q1];
+            const colval c0 = ld_b12(b12, q0), c1 = ld_b12(b12, q1);
+            pb0 = c0.val; pb1 = c1.val;
+            pc0 = c0.col; pc1 = c1.col;
         }
     }
     __syncthreads();
@@ -1622,13 +1655,14 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 double r0 = pb0, r1 = pb1;
                 if (!pipelined) {
                     const int p0 = v0 ? s + pi : 0, p1 = v1 ? s + pi + LA : 0;
-                    r0 = b_val[p0]; r1 = b_val[p1];
-                    q0 = b_ix[p0]; q1 = b_ix[p1];
+                    const colval c0 = ld_b12(b12, p0), c1 = ld_b12(b12, p1);
+                    r0 = c0.val; r1 = c1.val;
+                    q0 = c0.col; q1 = c1.col;
                 }
                 const int rem = lane < E ? len - 2 * LA : 0;
                 unsigned long long mask_c = __ballot(rem > 256);
                 // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
-                wave_flat_sweep<true>(b_ix, b_val, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
+                wave_flat_sweep<true>(nullptr, b12, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
                                       [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); },
                                       [&] {
                                           dense_add(acc, flags, q0, cbase, a * r0, v0);
@@ -1649,8 +1683,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     for (int q = 0; q < 4; q++) {
                         const int i = 64 * q + lane;
                         const int ic = i < rr ? i : rr - 1;
-                        bq[q] = b_val[ss + ic];
-                        cq[q] = b_ix[ss + ic];
+                        const colval cv = ld_b12(b12, ss + ic);
+                        bq[q] = cv.val;
+                        cq[q] = cv.col;
                     }
                     for (int i0 = 0; i0 < rr; i0 += 256) {
                         int cn[4];
@@ -1659,8 +1694,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                         for (int q = 0; q < 4; q++) {
                             const int i = i0 + 256 + 64 * q + lane;
                             const int ic = i < rr ? i : rr - 1;
-                            bn[q] = b_val[ss + ic];
-                            cn[q] = b_ix[ss + ic];
+                            const colval cv = ld_b12(b12, ss + ic);
+                            bn[q] = cv.val;
+                            cn[q] = cv.col;
                         }
 #pragma unroll
                         for (int q = 0; q < 4; q++) dense_add(acc, flags, cq[q], cbase, aa * bq[q], i0 + 64 * q + lane < rr);
@@ -1674,8 +1710,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 // see above; after the last window they read position 0)
                 const int len = w + 1 < nbase ? t_nxt - t_cur : 0;
                 const int q0 = pi < len ? t_cur + pi : 0, q1 = pi + LA < len ? t_cur + pi + LA : 0;
-                pb0 = b_val[q0]; pb1 = b_val[q1];
-                pc0 = b_ix[q0]; pc1 = b_ix[q1];
+                const colval c0 = ld_b12(b12, q0), c1 = ld_b12(b12, q1);
+                pb0 = c0.val; pb1 = c1.val;
+                pc0 = c0.col; pc1 = c1.col;
             }
             DENSE_STAMP(0)
             __syncthreads();
@@ -1992,6 +2029,7 @@ struct Bins {
     long long n_s, n_t, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
     int32_t* winptr;
     int shift, nbase;
+    uint32_t* b12;       // numeric: B as 12-byte {column id, value} records for the window kernels
     bool slab;           // the window rows take the launches over B's slab order
     int nslots;          // (slab) numbered rows
     bool rebuilt;        // (slab) a numeric call found no matching plan: the slots are this call's own, without counts yet
@@ -2140,6 +2178,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     const unsigned long long dig_a = (unsigned long long)h[CNT_DIG_A], dig_b = (unsigned long long)h[CNT_DIG_B];
     out->wcnt = nullptr;
     out->winptr = nullptr;
+    out->b12 = nullptr;
     if (mode == BINS_PRODUCTS) {
         phase_end(ctx, ph);
         return SPMM_OK;
@@ -2165,6 +2204,13 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
                                out->shift, out->nbase, out->winptr);
             has_table = true;
         }
+    }
+    // numeric: B's entries as 12-byte records (the values are this call's)
+    if (mode == BINS_NUMERIC && !slab && (out->n_w > 0 || out->n_g > 0) && B->nnz > 0) {
+        CHK(ws(ctx, WS_B12, (size_t)B->nnz * 3 + 4, &out->b12));
+        int64_t g = ((int64_t)B->nnz + 255) / 256;
+        if (g > 256 * 16) g = 256 * 16;
+        hipLaunchKernelGGL(k_pack_b12, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->indices, B->data, (int64_t)B->nnz, out->b12);
     }
     phase_end(ctx, ph);
     // the slab order of B, likewise
@@ -2197,7 +2243,7 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
-                       A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
+                       A->indices, A->data, B->indices, bins.b12, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
                        c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
                        (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0);
     return SPMM_OK;
@@ -2233,7 +2279,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         // rows with very many entries first, each shared by giant_tasks workgroups
         const int n_shared = (int)bins.n_g * ctx->giant_tasks;
         hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + bins.n_dense)), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr,
-                           A->indices, A->data, B->indices, B->data, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
+                           A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
                            c_val, ctx->win_dbg >> 8, stamps, bins.list_g, n_shared, ctx->giant_tasks, ctx->giant_chunk,
                            bins.gslot, bins.wcnt);
         phase_end(ctx, phd);
