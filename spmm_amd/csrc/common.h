@@ -98,6 +98,8 @@ struct spmm_ctx {
     int giant_len = 8192;   // dense rows with more entries of A than this are the ones that get split
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
+    int chain_persistent = 1;      // the greedy block chain in one persistent launch (0: one launch per step)
+    int chain_max_spins = 1 << 22; // polls of a workgroup waiting for the others before it gives up
     int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
     long long table_max_bytes = 16ll << 30;
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)

@@ -46,6 +46,8 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     if (const char* e = getenv("SPMM_GIANT_CHUNK")) c->giant_chunk = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("SPMM_SPLIT_GIANT")) c->split_giant = atoi(e);
     if (const char* e = getenv("SPMM_GIANT_LEN")) c->giant_len = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("SPMM_CHAIN_PERSISTENT")) c->chain_persistent = atoi(e);
+    if (const char* e = getenv("SPMM_CHAIN_MAX_SPINS")) c->chain_max_spins = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("SPMM_SLAB")) c->slab_mode = atoi(e);
     if (const char* e = getenv("SPMM_TABLE_MAX_GIB")) c->table_max_bytes = (long long)(atof(e) * (double)(1ll << 30));
     if (const char* e = getenv("SPMM_SLAB_WMAX")) { int v = atoi(e) & ~63; c->slab_wmax = v < 64 ? 64 : v > 15360 ? 15360 : v; }

@@ -308,6 +308,162 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
     }
 }
 
+// The same chain in ONE launch: BC_TILES workgroups stay resident and walk the steps together.  Per step every
+// workgroup counts its tile, publishes the count and arrives on a counter; the workgroup whose arrival is the last of
+// the step decides (as above) and publishes the new state and the step number; the others wait for that number.
+// Everything that crosses workgroups goes through agent-scope atomics and cache-bypassing (sc1) loads and stores, each
+// publication drained (s_waitcnt vmcnt(0)) before the counter or step number that announces it.  Waiting is bounded:
+// a workgroup that waits too long (the grid is not co-resident, e.g. on a shared GPU) raises `timeout`, every
+// workgroup leaves, and the host runs the chain step by step instead.
+struct bc_pstate {
+    int32_t s0, pos, cnt, nb, done, overflow;   // the chain's state after `gen` steps
+    int32_t gen, timeout, arrive, pad[7];
+    int32_t tile_cnt[2][BC_TILES];
+};
+__device__ __forceinline__ int32_t ld_sc1(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void k_block_chain_pinit(bc_pstate* st, int32_t* __restrict__ bsize, int32_t cap) {
+    if (threadIdx.x == 0) {
+        st->s0 = st->pos = st->cnt = 0;
+        st->nb = 1;
+        st->done = 0;
+        st->overflow = cap < 2 ? 1 : 0;
+        st->gen = st->timeout = st->arrive = 0;
+        if (cap >= 1) bsize[0] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
+                                                                       const int32_t* __restrict__ prev, int32_t threshold,
+                                                                       int32_t* __restrict__ bsize, int32_t cap, bc_pstate* st,
+                                                                       int32_t max_spins) {
+    static_assert(BC_TILES == 64, "one lane per tile count");
+    __shared__ int32_t tmp[BC_THREADS / 64 + 1];
+    __shared__ int32_t sh[8];          // s0, pos, cnt, nb, stop, last, hit, cut
+    const int tid = threadIdx.x;
+    int s0 = 0, pos = 0, cnt = 0, nb = 1;
+    if (tid == 0) sh[4] = (ld_sc1(&st->overflow) != 0) ? 1 : 0;
+    __syncthreads();
+    if (sh[4]) return;
+    for (int step = 0;; step++) {
+        // ---- this workgroup's tile ------------------------------------------------------------------------------------
+        {
+            const int q0 = pos + (int)blockIdx.x * BC_TILE + tid * BC_ITEMS;
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < BC_ITEMS; j++) c += (q0 + j < nnz && prev[q0 + j] < s0) ? 1 : 0;
+            c = wave_reduce_sum(c);
+            if ((tid & 63) == 0) tmp[tid >> 6] = c;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int i = 0; i < BC_THREADS / 64; i++) tot += tmp[i];
+                st_sc1(&st->tile_cnt[step & 1][blockIdx.x], tot);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int old = atomicAdd(&st->arrive, 1);
+                sh[5] = old == BC_TILES * (step + 1) - 1 ? 1 : 0;
+            }
+            __syncthreads();
+        }
+        if (sh[5]) {
+            // ---- the last arrival of the step decides ---------------------------------------------------------------------
+            if (tid < 64) {
+                const int c = ld_sc1(&st->tile_cnt[step & 1][tid]);
+                int inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(inc, d, 64);
+                    inc += tid >= d ? o : 0;
+                }
+                const unsigned long long reach = __ballot(cnt + inc >= threshold);
+                const int first = reach ? __ffsll(reach) - 1 : -1;
+                if (tid == (first < 0 ? 63 : first)) {
+                    sh[6] = first;                       // deciding tile, or -1
+                    sh[7] = first < 0 ? inc : inc - c;   // new columns of the tiles before it (all tiles when none decides)
+                }
+            }
+            __syncthreads();
+            const int hit = sh[6], run = sh[7];
+            __syncthreads();
+            int n_s0 = s0, n_pos = pos, n_cnt = cnt, n_nb = nb, n_done = 0, n_over = 0;
+            if (hit < 0) {
+                n_cnt = cnt + run;
+                n_pos = pos + BC_TILES * BC_TILE;
+                if (n_pos >= nnz) {                                      // end of the stream: the last block takes the rest
+                    if (nb >= cap) n_over = 1; else if (tid == 0) bsize[nb] = nrow;
+                    n_done = 1;
+                }
+            } else {
+                const int target = threshold - cnt - run;
+                const int q0 = pos + hit * BC_TILE + tid * BC_ITEMS;
+                unsigned mask = 0;
+#pragma unroll
+                for (int j = 0; j < BC_ITEMS; j++)
+                    if (q0 + j < nnz && prev[q0 + j] < s0) mask |= 1u << j;
+                const int c = __popc(mask);
+                int tot;
+                const int ex = block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
+                if (ex < target && target <= ex + c) {
+                    unsigned m = mask;
+                    for (int k = target - ex; k > 1; k--) m &= m - 1u;
+                    sh[7] = q0 + (__ffs(m) - 1);
+                }
+                __syncthreads();
+                int lo = 0, hi = nrow + 1;
+                const int v = sh[7];
+                while (hi - lo > 1) {                                    // 1024-way search over the row pointers
+                    const int stp = (hi - lo + BC_THREADS - 1) / BC_THREADS;
+                    const int idx = lo + tid * stp;
+                    const int cc = __syncthreads_count(idx < hi && r_ip[idx] <= v);
+                    const int nlo = lo + (cc - 1) * stp;
+                    hi = lo + cc * stp < hi ? lo + cc * stp : hi;
+                    lo = nlo;
+                }
+                const int r = lo;
+                if (nb + 1 >= cap) {
+                    n_over = 1;
+                } else {
+                    if (tid == 0) bsize[nb] = r + 1;
+                    n_nb = nb + 1;
+                    const int ns = r_ip[r + 1];
+                    n_s0 = n_pos = ns;
+                    n_cnt = 0;
+                    if (ns >= nnz) {                                     // the stream ends with this cut
+                        if (nb + 2 > cap) n_over = 1; else if (tid == 0) bsize[nb + 1] = nrow;
+                        n_done = 1;
+                    }
+                }
+            }
+            if (tid == 0) {
+                st_sc1(&st->s0, n_s0); st_sc1(&st->pos, n_pos); st_sc1(&st->cnt, n_cnt); st_sc1(&st->nb, n_nb);
+                st_sc1(&st->done, n_done); st_sc1(&st->overflow, n_over);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_sc1(&st->gen, step + 1);
+            }
+        }
+        // ---- everybody: the state after this step ----------------------------------------------------------------------------
+        if (tid == 0) {
+            int spins = 0, stop = 0;
+            while (ld_sc1(&st->gen) < step + 1) {
+                if (ld_sc1(&st->timeout) || ++spins > max_spins) {
+                    st_sc1(&st->timeout, 1);
+                    stop = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            sh[0] = ld_sc1(&st->s0); sh[1] = ld_sc1(&st->pos); sh[2] = ld_sc1(&st->cnt); sh[3] = ld_sc1(&st->nb);
+            sh[4] = (stop || ld_sc1(&st->done) || ld_sc1(&st->overflow)) ? 1 : 0;
+        }
+        __syncthreads();
+        s0 = sh[0]; pos = sh[1]; cnt = sh[2]; nb = sh[3];
+        const int stop = sh[4];
+        __syncthreads();
+        if (stop) return;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Panel boundaries of one block, v8sort.h:49-73.  Rows are visited in steps of 8 (step j looks at
 // row 8j); a boundary is pushed at step j when the block-local nnz offset x_j of that row exceeds
@@ -578,10 +734,34 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
     CHK(ws(ctx, WS_COUNTERS, sizeof(bc_state) / sizeof(int32_t) + 1, (int32_t**)&st));
     if (nnz > 0)
         hipLaunchKernelGGL(k_prev_from_sorted, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, prev);
+    int32_t* h = (int32_t*)ctx->pinned;
+    if (ctx->chain_persistent) {
+        // the whole chain in one launch of BC_TILES resident workgroups; falls through to the stepwise form when a
+        // workgroup waited too long for the others (a grid that is not co-resident)
+        bc_pstate* ps;
+        CHK(ws(ctx, WS_MISC3, sizeof(bc_pstate) / sizeof(int32_t) + 1, (int32_t**)&ps));
+        hipLaunchKernelGGL(k_block_chain_pinit, dim3(1), dim3(64), 0, ctx->stream, ps, bsize, cap);
+        hipLaunchKernelGGL(k_block_chain_persistent, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, prev, threshold,
+                           bsize, cap, ps, ctx->chain_max_spins);
+        HIPCHK(hipMemcpyAsync(h, ps, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!h[7]) {     // no timeout
+            phase_end(ctx, ph);
+            if (h[5]) {
+                spmm_set_error("gen_blocks: more than %d blocks; the block list is too small", cap - 1);
+                return SPMM_E_CAPACITY;
+            }
+            if (!h[4]) {
+                spmm_set_error("gen_blocks: the block chain ended without finishing");
+                return SPMM_E_HIP;
+            }
+            *bnum_host = h[3];
+            return SPMM_OK;
+        }
+    }
     hipLaunchKernelGGL(k_block_chain_init, dim3(1), dim3(64), 0, ctx->stream, st, bsize, cap);
     // one launch per step of the chain; the number of steps (blocks + windows without a cut) is only
     // known on the device, so steps are queued in batches and the state is read back after each
-    int32_t* h = (int32_t*)ctx->pinned;
     // every step either cuts a block (at most nrow of them) or moves on by BC_TILES tiles
     const int64_t max_steps = (int64_t)nrow + (int64_t)nnz / (BC_TILES * BC_TILE) + 2;
     for (int64_t steps = 0;; steps += 128) {

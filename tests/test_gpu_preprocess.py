@@ -14,9 +14,26 @@ STAGES = ["seq_bitmap", "r_indptr", "r_indices", "r_data", "bsize_list", "panel_
           "out_seq_all", "b_indptr", "b_colidx_orig", "b_data", "b_local", "keys", "seq_offset", "seq_input", "rseq"]
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = capi.Context(0)
+# The greedy block chain as one persistent launch (default), as one launch per step, and as the persistent launch with a
+# spin limit of one poll, so that a workgroup gives up waiting for the others and the host falls back to the stepwise
+# form (every kernel still ends normally).
+CHAINS = {"persistent": {}, "stepwise": {"SPMM_CHAIN_PERSISTENT": "0"}, "persistent_gives_up": {"SPMM_CHAIN_MAX_SPINS": "1"}}
+
+
+@pytest.fixture(scope="module", params=list(CHAINS))
+def ctx(request):
+    import os
+    env = CHAINS[request.param]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = capi.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     yield c
     c.close()
 
