@@ -64,6 +64,10 @@ struct plan_cache {
     bool has_table = false;   // the window table of B was built (only products with window rows need it)
     bool has_slab = false;    // the slab order of B was built (likewise)
     bool slab = false;        // the plan is one without the window table
+    // the row lists of the last classification, reusable by a numeric call over the same rows of the same matrices
+    bool lists_valid = false;
+    int l_row_beg = 0, l_row_end = 0;
+    long long l_n_s = 0, l_n_t = 0, l_n_l = 0, l_n_m = 0, l_n_w = 0, l_n_g = 0, l_n_dense = 0, l_n_light = 0, l_products = 0;
 };
 
 // B in slab order (slab.hip): column windows, entries sorted by window, pieces with links.
@@ -96,12 +100,16 @@ struct spmm_ctx {
     long long light_max = -1;   // window rows with at most this many products use the small cursor workgroups (0 = none, < 0 = by the number of table windows)
     int giant_tasks = 16, giant_chunk = 1;   // workgroups per split row; consecutive table windows per turn
     int giant_len = 8192;   // dense rows with more entries of A than this are the ones that get split
+    // Dense rows in window-major order: every dense row is numbered by the symbolic call (per-window counts), a numeric
+    // workgroup takes major_chunk consecutive table windows of one row, and the grid runs through all rows of one chunk
+    // before the next chunk, so that the workgroups resident at one time read the same column range of B.
+    int giant_major = 1, major_chunk = 8;
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
     int chain_persistent = 1;      // the greedy block chain in one persistent launch (0: one launch per step)
     int chain_max_spins = 1 << 22; // polls of a workgroup waiting for the others before it gives up
     int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
-    long long table_max_bytes = 16ll << 30;
+    long long table_max_bytes = 96ll << 30;
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse

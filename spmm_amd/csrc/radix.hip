@@ -110,6 +110,37 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
     }
 }
 
+// Short inputs: one workgroup sorts (masked key, position) in LDS with a bitonic network; the position as the low half
+// of the compared word makes the order the stable one of the passes above, in one launch instead of five per pass.
+constexpr int SS_MAX = 8192;
+constexpr int SS_THREADS = 1024;
+template <bool HAS_VALS>
+__global__ void __launch_bounds__(SS_THREADS) k_small_sort(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n,
+                                                           int n2, uint32_t mask) {
+    __shared__ unsigned long long e[SS_MAX];
+    for (int i = threadIdx.x; i < n2; i += SS_THREADS)
+        e[i] = i < n ? ((unsigned long long)(keys_in[i] & mask) << 32) | (unsigned)i : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n2 >> 1); t += SS_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = e[i], b = e[l];
+                if ((a > b) == up) { e[i] = b; e[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += SS_THREADS) {
+        const unsigned src = (unsigned)e[i];
+        keys_out[i] = keys_in[src];
+        if (HAS_VALS) vals_out[i] = vals_in[src];
+    }
+}
+
 }  // namespace
 
 int dev_radix_sort_pairs(spmm_ctx* ctx, uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
@@ -119,6 +150,17 @@ int dev_radix_sort_pairs(spmm_ctx* ctx, uint32_t* keys_in, uint32_t* vals_in, ui
     const bool has_vals = vals_in != nullptr;
     int passes = (key_bits + 7) / 8;
     if (passes < 1) passes = 1;
+    if (n <= SS_MAX && keys_in != keys_out && (!has_vals || vals_in != vals_out)) {
+        int n2 = 1;
+        while (n2 < n) n2 <<= 1;
+        const uint32_t mask = passes >= 4 ? 0xffffffffu : ((1u << (8 * passes)) - 1u);
+        if (has_vals)
+            hipLaunchKernelGGL(k_small_sort<true>, dim3(1), dim3(SS_THREADS), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out, (int)n, n2, mask);
+        else
+            hipLaunchKernelGGL(k_small_sort<false>, dim3(1), dim3(SS_THREADS), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out, (int)n, n2, mask);
+        HIPCHK(hipGetLastError());
+        return SPMM_OK;
+    }
     int nb = (int)((n + RS_TILE - 1) / RS_TILE);
     int32_t* hist;
     CHK(ws(ctx, WS_RADIX_HIST, (size_t)256 * nb + 1, &hist));

@@ -135,23 +135,6 @@ __global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrow
     if (bad) counters[CNT_BAD] = 1;
 }
 
-__global__ void __launch_bounds__(256) k_check_sorted(int32_t nrow, int32_t ncol, const int32_t* __restrict__ ip,
-                                                      const int32_t* __restrict__ ix, long long* __restrict__ counters) {
-    int64_t nnz = ip[nrow];
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // position p is a violation when ix[p] < ix[p-1] and p is not the first entry of its row: a
-    // decreasing pair is legal only across a row boundary, which a binary search over indptr
-    // decides for the few candidates.  Column ids must also lie in [0, ncol).
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
-        if ((uint32_t)ix[p] >= (uint32_t)ncol) counters[CNT_BAD] = 1;
-        if (p > 0 && ix[p] < ix[p - 1]) {
-            int lo = 0, hi = nrow;   // find row r with ip[r] <= p < ip[r+1]
-            while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ip[mid] <= p) lo = mid; else hi = mid - 1; }
-            if (ip[lo] != p) counters[CNT_UNSORTED] = 1;
-        }
-    }
-}
-
 // Bin rows [row_beg,row_end) by P_i.  List positions are handed out per workgroup: the waves count their
 // rows of every class by ballot, one thread per class adds the workgroup's total to the global counter, and
 // a row's position is the workgroup's base + the count of the waves before its own + its rank in the wave.
@@ -169,6 +152,7 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
     enum { C_NONE = 0, C_G = 1, C_M = 2, C_W = 3, C_L = 4, C_S = 5, C_T = 6, C_DENSE = 7, C_LIGHT = 8, C_N = 9 };
     __shared__ int32_t wcnt[NW][C_N];
     __shared__ long long gbase[C_N];
+    __shared__ long long wprod[NW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
@@ -185,13 +169,14 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
         const bool is_win = p > ESC_R_CAP || (p > ESC_S_CAP && many_entries);   // the row takes the window kernels
         // Without the window table of B (slab != 0) every window row takes the launches over B's slab order: the
         // symbolic call numbers them all (giant_mode 1) and later calls on the same matrices keep the numbers.
+        // giant_mode 2 reads the numbers of the symbolic call; the other modes leave -1 for the rows they do not number
         if (slab && is_win && giant_mode == 1) {
             const int slot = (int)atomicAdd((unsigned long long*)&counters[CNT_GIANT_ALL], 1ull);
             gslot[row] = slot;
             slot_row[slot] = (int32_t)row;
-        }
-        if (!slab && giant_mode == 1 && is_win && p >= dense_thr && len_a > giant_len)
+        } else if (!slab && giant_mode == 1 && is_win && p >= dense_thr && len_a > giant_len)
             gslot[row] = (int)atomicAdd((unsigned long long*)&counters[CNT_GIANT_ALL], 1ull);
+        else if (giant_mode != 2) gslot[row] = -1;
         if (slab && is_win) cat = C_G;
         else if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) cat = C_G;
         else if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) cat = C_M;
@@ -216,7 +201,17 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
         const unsigned long long md = __ballot(dense), ml = __ballot(light);
         if (lane == 0) { wcnt[wv][C_DENSE] = __popcll(md); wcnt[wv][C_LIGHT] = __popcll(ml); }
     }
+    {
+        const long long s = wave_reduce_sum(p);
+        if (lane == 0) wprod[wv] = s;
+    }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        // one atomic per workgroup: thousands on one word would be the longest part of the kernel
+        long long s = 0;
+        for (int w = 0; w < NW; w++) s += wprod[w];
+        if (s) atomicAdd((unsigned long long*)&counters[CNT_PRODUCTS], (unsigned long long)s);
+    }
     if (threadIdx.x >= C_G && threadIdx.x < C_N) {
         const int c = threadIdx.x;
         const int slot = c == C_G ? CNT_GIANT : c == C_M ? CNT_ESC_M : c == C_W ? CNT_WIN : c == C_L ? CNT_ESC_L :
@@ -240,8 +235,6 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
             key_w[at] = 0xffffffffu - (uint32_t)(p > 0xffffffffll ? 0xffffffffll : p);   // ascending key = descending P
         }
     }
-    long long s = wave_reduce_sum(p);
-    if (lane == 0 && s) atomicAdd((unsigned long long*)&counters[CNT_PRODUCTS], (unsigned long long)s);
 }
 
 // Content digest of an int32 array (row pointers, column ids): what a numeric call compares with the symbolic
@@ -252,14 +245,45 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     x ^= x >> 33;
     return x;
 }
-__global__ void __launch_bounds__(256) k_struct_digest(const int32_t* __restrict__ a, int64_t n, unsigned long long salt,
-                                                       unsigned long long* __restrict__ out) {
+// check != 0 (the matrix is the right-hand one): also the test of the column ids just read.  They must lie in
+// [0, ncol) and ascend within a row: a position whose column id is below its predecessor's is legal only as the first
+// entry of a row, so the descents counted over the entries must equal the descents counted at the starts of the
+// non-empty rows; the difference goes to counters[CNT_UNSORTED].
+__global__ void __launch_bounds__(256) k_struct_digest(const int32_t* __restrict__ ip, int32_t nrow, const int32_t* __restrict__ ix,
+                                                       int64_t n_ix, unsigned long long* __restrict__ out, int check, int32_t ncol,
+                                                       long long* __restrict__ counters) {
+    // row pointers and column ids of one matrix in one launch; one atomic per workgroup (thousands of atomics on one
+    // word take longer than reading the arrays)
+    __shared__ unsigned long long part[4];
+    __shared__ long long dpart[4];
     unsigned long long h = 0;
+    long long descents = 0;
+    bool bad = false;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-        h += mix64((unsigned long long)(uint32_t)a[i] + ((unsigned long long)i + salt) * 0x9e3779b97f4a7c15ull);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= nrow; i += stride) {
+        const int s = ip[i];
+        h += mix64((unsigned long long)(uint32_t)s + ((unsigned long long)i + 0x1000000000ull) * 0x9e3779b97f4a7c15ull);
+        if (check && i < nrow && s > 0 && s < n_ix && s < ip[i + 1] && ix[s] < ix[s - 1]) descents--;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_ix; i += stride) {
+        const int c = ix[i];
+        h += mix64((unsigned long long)(uint32_t)c + ((unsigned long long)i + 0x2000000000ull) * 0x9e3779b97f4a7c15ull);
+        if (check) {
+            bad |= (uint32_t)c >= (uint32_t)ncol;
+            if (i > 0 && c < ix[i - 1]) descents++;
+        }
+    }
     h = wave_reduce_sum(h);
-    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+    descents = wave_reduce_sum(descents);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = h; dpart[threadIdx.x >> 6] = descents; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out, t);
+        const long long d = dpart[0] + dpart[1] + dpart[2] + dpart[3];
+        if (d) atomicAdd((unsigned long long*)&counters[CNT_UNSORTED], (unsigned long long)d);
+    }
+    if (bad) counters[CNT_BAD] = 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -1522,7 +1546,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg_arg,
                                                    unsigned long long* __restrict__ stamps, const int32_t* __restrict__ list_g,
                                                    int n_shared, int ntask_shared, int chunk,
-                                                   const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt) {
+                                                   const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt, int major_rows) {
     // The first n_shared workgroups work on the rows of list_g, ntask_shared workgroups per row: workgroup
     // t of a row takes the table windows t, t + ntask, ... (in chunks of `chunk`) and finds the place of a
     // window's entries in the row of C from the per-window counts of the symbolic phase (at most THREADS
@@ -1545,8 +1569,10 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     int32_t* pre = (int32_t*)((uint8_t*)(tmp + 2 * NW) + NW * 256);          // THREADS window offsets (shared rows)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int task = shared ? (int)(blockIdx.x % (unsigned)ntask) : 0;
-    const int row = shared ? list_g[blockIdx.x / (unsigned)ntask] : list[blockIdx.x - (unsigned)n_shared];
+    // major_rows > 0: the workgroups of one chunk of windows are neighbours in the grid (all rows, then the next chunk)
+    const int task = !shared ? 0 : major_rows > 0 ? (int)(blockIdx.x / (unsigned)major_rows) : (int)(blockIdx.x % (unsigned)ntask);
+    const int row = !shared ? list[blockIdx.x - (unsigned)n_shared]
+                            : list_g[major_rows > 0 ? blockIdx.x % (unsigned)major_rows : blockIdx.x / (unsigned)ntask];
     const int a0 = a_ip[row];
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
@@ -1555,7 +1581,10 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     const int lgE = dbg ? dbg : lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
     const int E = 1 << lgE, LA = 64 >> lgE;
     const int npass = (lenA + E * NW - 1) / (E * NW);
-    const bool cached = npass == 1 && ntask == 1;
+    // major_rows > 0: the workgroup has one run of `chunk` consecutive windows (chunk a multiple of DENSE_TQ)
+    const bool one_run = ntask == 1 || major_rows > 0;
+    const int w_first = major_rows > 0 && shared ? task * chunk : 0;
+    const bool cached = npass == 1 && one_run;
     const int el = lane & (E - 1), pi = lane >> lgE;
     const int nsub = shift > 14 ? 1 << (shift - 14) : 1;
     const bool pipelined = cached && nsub == 1;
@@ -1587,8 +1616,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
         if (have) {
             Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
             av = a_val[a0 + e];
-            t_cur = Tp[0];
-            t_nxt = Tp[1];
+            t_cur = Tp[w_first];
+            t_nxt = Tp[w_first + 1];
         }
         if (pipelined) {
             // unconditional loads (position 0 when there is no such product): the compiler can then count
@@ -1610,8 +1639,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     int flip = 0;
     for (int wi = 0;; wi++) {
         // workgroup t of a shared row takes chunks t, t + ntask, ... of `chunk` consecutive table windows
-        const int w = ntask > 1 ? ((wi / chunk) * ntask + task) * chunk + wi % chunk : wi;
-        if (w >= nbase) break;
+        const int w = one_run ? w_first + wi : ((wi / chunk) * ntask + task) * chunk + wi % chunk;
+        if (w >= nbase || (ntask > 1 && one_run && wi >= chunk)) break;
         if (ntask > 1) out = out_row + pre[w];
         int s_c = 0, len_c = 0;
         if (cached) {
@@ -2094,40 +2123,39 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     out->slab = slab;
     HIPCHK(hipMemsetAsync(counters, 0, sizeof(long long) * CNT_N, ctx->stream));
     long long* h = (long long*)ctx->pinned;
-    // content digests of the structure arrays
+    const bool same = A->indptr == B->indptr && A->indices == B->indices && A->nrow == B->nrow && A->nnz == B->nnz && A->ncol == B->ncol;
+    // content digests of the structure arrays (B's is A's when the two views are the same arrays), and with B's the
+    // test that its column ids are in range and ascending within each row
     {
         unsigned long long* dg = (unsigned long long*)counters;
-        auto digest = [&](const int32_t* a, int64_t n, unsigned long long salt, int slot) {
-            if (n <= 0) return;
-            int64_t g = (n + 255) / 256;
-            if (g > 256 * 16) g = 256 * 16;
-            hipLaunchKernelGGL(k_struct_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, a, n, salt, dg + slot);
+        auto digest = [&](const spmm_csr* M, int slot, int check) {
+            int64_t g = ((int64_t)M->nnz + M->nrow + 256) / (256 * 8);
+            if (g > 512) g = 512;
+            if (g < 1) g = 1;
+            hipLaunchKernelGGL(k_struct_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, M->indptr, M->nrow, M->indices,
+                               (int64_t)M->nnz, dg + slot, check, M->ncol, counters);
         };
-        digest(A->indptr, (int64_t)A->nrow + 1, 0x1000000000ull, CNT_DIG_A);
-        digest(A->indices, A->nnz, 0x2000000000ull, CNT_DIG_A);
-        digest(B->indptr, (int64_t)B->nrow + 1, 0x1000000000ull, CNT_DIG_B);
-        digest(B->indices, B->nnz, 0x2000000000ull, CNT_DIG_B);
+        if (!same) digest(A, CNT_DIG_A, 0);
+        digest(B, CNT_DIG_B, 1);
     }
     bool hit = false;
     if (!fresh && pc.valid && pc.slab == slab && pc.a_nrow == A->nrow && pc.a_nnz == A->nnz && pc.b_nrow == B->nrow &&
         pc.b_ncol == B->ncol && pc.b_nnz == B->nnz) {
         HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (same) h[CNT_DIG_A] = h[CNT_DIG_B];
         hit = (unsigned long long)h[CNT_DIG_A] == pc.dig_a && (unsigned long long)h[CNT_DIG_B] == pc.dig_b;
     }
+    // the lists of the last classification serve this call when it is over the same rows of the same matrices
+    const bool reuse = hit && pc.lists_valid && pc.l_row_beg == row_beg && pc.l_row_end == row_end;
     pc.valid = false;
+    pc.lists_valid = false;
     out->rebuilt = !fresh && !hit;
     if (!hit && nrow > 0) {
         int64_t nb = ((int64_t)nrow + 15) / 16;
         if (nb > 256 * 64) nb = 256 * 64;
         hipLaunchKernelGGL(k_row_products, dim3((unsigned)nb), dim3(256), 0, ctx->stream, nrow, B->nrow, A->indptr,
                            A->indices, B->indptr, out->prod, counters);
-    }
-    if (!hit && B->nnz > 0) {
-        int64_t g = ((int64_t)B->nnz + 255) / 256;
-        if (g > 256 * 16) g = 256 * 16;
-        hipLaunchKernelGGL(k_check_sorted, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->nrow, B->ncol, B->indptr,
-                           B->indices, counters);
     }
     int32_t nr = row_end - row_beg;
     const long long dense_thr = dense_threshold(ctx, out->nbase);
@@ -2139,8 +2167,9 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     // Numbered rows.  With the table: the symbolic call numbers the dense rows with very many entries, and a numeric
     // call on the same matrices splits them when the symbolic kernel left their per-window counts.  With the slab
     // order: every window row is numbered, by the symbolic call or, failing a matching one, by the numeric call.
-    const bool can_count = ctx->split_giant && ctx->sym_cfg == 0 && out->shift <= 20 && out->nbase >= 2 * ctx->giant_tasks * ctx->giant_chunk &&
-                           out->nbase <= 1024;
+    const bool major = ctx->giant_major && out->nbase >= 2 * ctx->major_chunk;
+    const bool can_count = ctx->split_giant && ctx->sym_cfg == 0 && out->shift <= 20 &&
+                           (major || out->nbase >= 2 * ctx->giant_tasks * ctx->giant_chunk) && out->nbase <= 1024;
     int giant_mode;
     if (slab) giant_mode = hit ? 2 : 1;
     else giant_mode = fresh ? (can_count ? 1 : 0) : (hit && pc.has_wcnt ? 2 : 0);
@@ -2149,31 +2178,36 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         pc.has_wcnt = false;
         pc.n_giant = 0;
     }
-    if (!hit) HIPCHK(hipMemsetAsync(out->gslot, 0xff, sizeof(int32_t) * ((size_t)nrow + 1), ctx->stream));
-    if (nr > 0)
-        hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
-                           out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
-                           ctx->giant_len, out->gslot, list_g0, (slab && mode != BINS_PRODUCTS) ? 1 : 0, out->slot_row, key_g0, counters);
-    HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (h[CNT_BAD]) {
-        spmm_set_error("spgemm: a column id of A is outside [0, B.nrow) or one of B outside [0, B.ncol)");
-        return SPMM_E_ARG;
+    if (!reuse) {
+        if (nr > 0)
+            hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
+                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
+                               major ? 0 : ctx->giant_len, out->gslot, list_g0, (slab && mode != BINS_PRODUCTS) ? 1 : 0, out->slot_row, key_g0, counters);
+        HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (same) h[CNT_DIG_A] = h[CNT_DIG_B];
+        if (h[CNT_BAD]) {
+            spmm_set_error("spgemm: a column id of A is outside [0, B.nrow) or one of B outside [0, B.ncol)");
+            return SPMM_E_ARG;
+        }
+        if (h[CNT_UNSORTED]) {
+            spmm_set_error("spgemm: B has a row whose column ids are not ascending");
+            return SPMM_E_UNSORTED;
+        }
+        out->n_s = h[CNT_ESC_S];
+        out->n_t = h[CNT_ESC_T];
+        out->n_l = h[CNT_ESC_L];
+        out->n_m = h[CNT_ESC_M];
+        out->n_w = h[CNT_WIN];
+        out->n_dense = h[CNT_DENSE];
+        out->n_light = h[CNT_LIGHT];
+        out->n_g = h[CNT_GIANT];
+        out->products = h[CNT_PRODUCTS];
+        if (giant_mode == 1) pc.n_giant = (int)h[CNT_GIANT_ALL];
+    } else {
+        out->n_s = pc.l_n_s; out->n_t = pc.l_n_t; out->n_l = pc.l_n_l; out->n_m = pc.l_n_m; out->n_w = pc.l_n_w;
+        out->n_dense = pc.l_n_dense; out->n_light = pc.l_n_light; out->n_g = pc.l_n_g; out->products = pc.l_products;
     }
-    if (h[CNT_UNSORTED]) {
-        spmm_set_error("spgemm: B has a row whose column ids are not ascending");
-        return SPMM_E_UNSORTED;
-    }
-    out->n_s = h[CNT_ESC_S];
-    out->n_t = h[CNT_ESC_T];
-    out->n_l = h[CNT_ESC_L];
-    out->n_m = h[CNT_ESC_M];
-    out->n_w = h[CNT_WIN];
-    out->n_dense = h[CNT_DENSE];
-    out->n_light = h[CNT_LIGHT];
-    out->n_g = h[CNT_GIANT];
-    out->products = h[CNT_PRODUCTS];
-    if (giant_mode == 1) pc.n_giant = (int)h[CNT_GIANT_ALL];
     out->nslots = pc.n_giant;
     const unsigned long long dig_a = (unsigned long long)h[CNT_DIG_A], dig_b = (unsigned long long)h[CNT_DIG_B];
     out->wcnt = nullptr;
@@ -2189,9 +2223,9 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
             HIPCHK(hipMemsetAsync(out->wcnt, 0, sizeof(uint32_t) * ((size_t)pc.n_giant * out->nbase + 1), ctx->stream));
         }
     }
-    if (out->n_w > 0)
+    if (out->n_w > 0 && !reuse)
         CHK(dev_radix_sort_pairs(ctx, key_w0, (uint32_t*)list_w0, key_w1, (uint32_t*)out->list_w, out->n_w, 32));
-    if (out->n_g > 0)
+    if (out->n_g > 0 && !reuse)
         CHK(dev_radix_sort_pairs(ctx, key_g0, (uint32_t*)list_g0, key_g1, (uint32_t*)out->list_g, out->n_g, 32));
     // the window table of B, once per pair of matrices and only when some row takes the table's kernels
     bool has_table = hit && pc.has_table;
@@ -2227,6 +2261,12 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     pc.dig_a = dig_a; pc.dig_b = dig_b;
     pc.a_nrow = A->nrow; pc.a_nnz = A->nnz; pc.b_nrow = B->nrow; pc.b_ncol = B->ncol; pc.b_nnz = B->nnz;
     pc.valid = fresh || hit;       // a numeric call that had to rebuild leaves nothing a later call could trust
+    // A numeric call classifies as this call did unless it takes numbered dense rows out of the window list
+    // (table path with rows numbered by the symbolic call).
+    pc.lists_valid = pc.valid && (slab || pc.n_giant == 0);
+    pc.l_row_beg = row_beg; pc.l_row_end = row_end;
+    pc.l_n_s = out->n_s; pc.l_n_t = out->n_t; pc.l_n_l = out->n_l; pc.l_n_m = out->n_m; pc.l_n_w = out->n_w; pc.l_n_g = out->n_g;
+    pc.l_n_dense = out->n_dense; pc.l_n_light = out->n_light; pc.l_products = out->products;
     HIPCHK(hipGetLastError());
     return SPMM_OK;
 }
@@ -2277,11 +2317,14 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
         // rows with very many entries first, each shared by giant_tasks workgroups
-        const int n_shared = (int)bins.n_g * ctx->giant_tasks;
+        const bool major = ctx->giant_major && bins.nbase >= 2 * ctx->major_chunk;
+        const int gchunk = major ? ctx->major_chunk : ctx->giant_chunk;
+        const int gtasks = major ? (bins.nbase + gchunk - 1) / gchunk : ctx->giant_tasks;
+        const int n_shared = (int)bins.n_g * gtasks;
         hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + bins.n_dense)), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr,
                            A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
-                           c_val, ctx->win_dbg >> 8, stamps, bins.list_g, n_shared, ctx->giant_tasks, ctx->giant_chunk,
-                           bins.gslot, bins.wcnt);
+                           c_val, ctx->win_dbg >> 8, stamps, bins.list_g, n_shared, gtasks, gchunk,
+                           bins.gslot, bins.wcnt, major ? (int)bins.n_g : 0);
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;
         bins.n_w -= bins.n_dense;
