@@ -104,6 +104,7 @@ struct spmm_ctx {
     // workgroup takes major_chunk consecutive table windows of one row, and the grid runs through all rows of one chunk
     // before the next chunk, so that the workgroups resident at one time read the same column range of B.
     int giant_major = 1, major_chunk = 8;
+    long long max_grid_threads = (1ll << 32) - 1;   // grid dimension x workgroup size of one launch (lower: launches in slices)
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
     int chain_persistent = 1;      // the greedy block chain in one persistent launch (0: one launch per step)

@@ -45,6 +45,7 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     if (const char* e = getenv("SPMM_GIANT_TASKS")) c->giant_tasks = atoi(e) > 1 ? atoi(e) : 2;
     if (const char* e = getenv("SPMM_GIANT_CHUNK")) c->giant_chunk = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("SPMM_GIANT_MAJOR")) c->giant_major = atoi(e);
+    if (const char* e = getenv("SPMM_MAX_GRID_THREADS")) { long long v = atoll(e); if (v >= 1024 && v < (1ll << 32)) c->max_grid_threads = v; }
     if (const char* e = getenv("SPMM_MAJOR_CHUNK")) c->major_chunk = atoi(e) > 0 ? (atoi(e) + 3) & ~3 : 4;   // whole turns of table-bound loads
     if (const char* e = getenv("SPMM_SPLIT_GIANT")) c->split_giant = atoi(e);
     if (const char* e = getenv("SPMM_GIANT_LEN")) c->giant_len = atoi(e) > 0 ? atoi(e) : 1;

@@ -2271,6 +2271,15 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     return SPMM_OK;
 }
 
+// A grid dimension times the workgroup size must stay below 2^32 threads: launches over a list of n rows (one
+// workgroup of `threads` per `per_wg` rows) go out in slices of f(first row of the slice, rows of the slice).
+template <typename F>
+void for_row_slices(const spmm_ctx* ctx, long long n, int threads, int per_wg, F&& f) {
+    long long max_rows = (ctx->max_grid_threads / threads) * per_wg;
+    if (max_rows < per_wg) max_rows = per_wg;
+    for (long long off = 0; off < n; off += max_rows) f(off, n - off < max_rows ? n - off : max_rows);
+}
+
 template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC>
 int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins, int32_t* rowcnt,
                const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
@@ -2282,10 +2291,12 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     auto kern = ctx->win_stamps ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)bins.n_w), dim3(THREADS), lds, ctx->stream, bins.list_w, A->indptr,
-                       A->indices, A->data, B->indices, bins.b12, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
-                       c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
-                       (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0);
+    for_row_slices(ctx, bins.n_w, THREADS, 1, [&](long long off, long long cnt) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(THREADS), lds, ctx->stream, bins.list_w + off, A->indptr,
+                           A->indices, A->data, B->indices, bins.b12, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
+                           c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
+                           (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0);
+    });
     return SPMM_OK;
 }
 
@@ -2320,11 +2331,22 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         const bool major = ctx->giant_major && bins.nbase >= 2 * ctx->major_chunk;
         const int gchunk = major ? ctx->major_chunk : ctx->giant_chunk;
         const int gtasks = major ? (bins.nbase + gchunk - 1) / gchunk : ctx->giant_tasks;
-        const int n_shared = (int)bins.n_g * gtasks;
-        hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + bins.n_dense)), dim3(1024), dl, ctx->stream, bins.list_w, A->indptr,
-                           A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
-                           c_val, ctx->win_dbg >> 8, stamps, bins.list_g, n_shared, gtasks, gchunk,
-                           bins.gslot, bins.wcnt, major ? (int)bins.n_g : 0);
+        auto launch = [&](const int32_t* list_g, long long n_g, const int32_t* list_w, long long n_dense) {
+            const int n_shared = (int)(n_g * gtasks);
+            hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + n_dense)), dim3(1024), dl, ctx->stream, list_w, A->indptr,
+                               A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
+                               c_val, ctx->win_dbg >> 8, stamps, list_g, n_shared, gtasks, gchunk,
+                               bins.gslot, bins.wcnt, major ? (int)n_g : 0);
+        };
+        const long long max_wg = ctx->max_grid_threads / 1024 > 0 ? ctx->max_grid_threads / 1024 : 1;
+        if (bins.n_g * gtasks + bins.n_dense <= max_wg) launch(bins.list_g, bins.n_g, bins.list_w, bins.n_dense);
+        else {
+            // more workgroups than one grid dimension holds: the shared rows in slices, then the others
+            const long long per = max_wg / gtasks > 0 ? max_wg / gtasks : 1;
+            for (long long off = 0; off < bins.n_g; off += per)
+                launch(bins.list_g + off, bins.n_g - off < per ? bins.n_g - off : per, bins.list_w, 0);
+            for_row_slices(ctx, bins.n_dense, 1024, 1, [&](long long off, long long cnt) { launch(bins.list_g, 0, bins.list_w + off, cnt); });
+        }
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;
         bins.n_w -= bins.n_dense;
@@ -2335,8 +2357,10 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         static_assert(sl <= 160 * 1024, "LDS budget of one CU");
         auto ks = k_symd<1024>;
         HIPCHK(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
-        hipLaunchKernelGGL(ks, dim3((unsigned)bins.n_w), dim3(1024), sl, ctx->stream, bins.list_w, A->indptr, A->indices,
-                           B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt, bins.gslot, bins.wcnt);
+        for_row_slices(ctx, bins.n_w, 1024, 1, [&](long long off, long long cnt) {
+            hipLaunchKernelGGL(ks, dim3((unsigned)cnt), dim3(1024), sl, ctx->stream, bins.list_w + off, A->indptr, A->indices,
+                               B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt, bins.gslot, bins.wcnt);
+        });
         ctx->plan.has_wcnt = bins.wcnt != nullptr;   // the numeric call may now split the numbered rows
         phase_end(ctx, phs);
         bins.n_w = 0;
@@ -2369,27 +2393,37 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         static_assert(rl <= 160 * 1024, "LDS budget of one CU");
         auto kr = k_escr<RT, ESC_R_CAP, NUMERIC>;
         HIPCHK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-        hipLaunchKernelGGL(kr, dim3((unsigned)bins.n_m), dim3(RT), rl, ctx->stream, bins.list_m, A->indptr, A->indices, A->data,
-                           B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
-                           bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+        for_row_slices(ctx, bins.n_m, RT, 1, [&](long long off, long long cnt) {
+            hipLaunchKernelGGL(kr, dim3((unsigned)cnt), dim3(RT), rl, ctx->stream, bins.list_m + off, A->indptr, A->indices, A->data,
+                               B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
+                               bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+        });
     }
     if (bins.n_l > 0) {
         constexpr size_t rl = escr_lds_bytes<512, ESC_L_CAP, NUMERIC>();
         static_assert(2 * rl <= 160 * 1024, "two workgroups per CU");
         auto kr = k_escr<512, ESC_L_CAP, NUMERIC>;
         HIPCHK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-        hipLaunchKernelGGL(kr, dim3((unsigned)bins.n_l), dim3(512), rl, ctx->stream, bins.list_l, A->indptr, A->indices, A->data,
-                           B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
-                           bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+        for_row_slices(ctx, bins.n_l, 512, 1, [&](long long off, long long cnt) {
+            hipLaunchKernelGGL(kr, dim3((unsigned)cnt), dim3(512), rl, ctx->stream, bins.list_l + off, A->indptr, A->indices, A->data,
+                               B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
+                               bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+        });
     }
     if (bins.n_s > 0)      // the back of the list
-        hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)bins.n_s), dim3(64), 0, ctx->stream,
-                           bins.list_s + ((size_t)A->nrow + 1 - (size_t)bins.n_s), A->indptr, A->indices, A->data, B->indptr, B->indices,
-                           B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
-    if (bins.n_t > 0)      // the front of the list, several rows per wave
-        hipLaunchKernelGGL((k_esc_rows<ESC_T_LANES, ESC_T_CAP, NUMERIC>), dim3((unsigned)((bins.n_t + 64 / ESC_T_LANES - 1) / (64 / ESC_T_LANES))), dim3(64), 0, ctx->stream, bins.list_s,
-                           (int)bins.n_t, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip,
-                           row_beg, c_ix, c_val);
+        for_row_slices(ctx, bins.n_s, 64, 1, [&](long long off, long long cnt) {
+            hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)cnt), dim3(64), 0, ctx->stream,
+                               bins.list_s + ((size_t)A->nrow + 1 - (size_t)bins.n_s) + off, A->indptr, A->indices, A->data, B->indptr,
+                               B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
+        });
+    if (bins.n_t > 0) {    // the front of the list, several rows per wave
+        constexpr int R = 64 / ESC_T_LANES;
+        for_row_slices(ctx, bins.n_t, 64, R, [&](long long off, long long cnt) {
+            hipLaunchKernelGGL((k_esc_rows<ESC_T_LANES, ESC_T_CAP, NUMERIC>), dim3((unsigned)((cnt + R - 1) / R)), dim3(64), 0, ctx->stream,
+                               bins.list_s + off, (int)cnt, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip,
+                               row_beg, c_ix, c_val);
+        });
+    }
     phase_end(ctx, ph_esc);
     HIPCHK(hipGetLastError());
     return SPMM_OK;

@@ -24,7 +24,9 @@ PLANS = {
     "dense_all": {"SPMM_DENSE_MIN": "1"},
     "dense_off": {"SPMM_DENSE_MIN": "0"},
     "cursor_sym_fixed_windows": {"SPMM_SYM_CFG": "1", "SPMM_ADAPTIVE": "0"},
-    "split_rows": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8"},
+    "split_rows": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8", "SPMM_GIANT_MAJOR": "0"},
+    "dense_window_major": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4"},
+    "sliced_launches": {"SPMM_MAX_GRID_THREADS": "8192", "SPMM_DENSE_MIN": "1"},
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
                            "SPMM_SLAB_THREADS": "256"},

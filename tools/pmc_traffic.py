@@ -31,8 +31,23 @@ for k in ("k_dense", "k_win<numeric>", "k_win<numeric, 256 threads>", "k_digest"
     rd = tot[k]["FETCH_SIZE"] * 1024 * 2 / n
     wr = tot[k]["WRITE_SIZE"] * 1024 / calls[k]["WRITE_SIZE"]
     kernels[k] = dict(fetch_kb_total=int(tot[k]["FETCH_SIZE"]), write_kb_total=int(tot[k]["WRITE_SIZE"]), launches=n,
-                      read_bytes_per_launch=int(rd), write_bytes_per_launch=int(wr), hbm_bytes_per_launch=int(rd + wr))
+                      read_bytes_per_launch_fetch_size_doubled=int(rd), write_bytes_per_launch=int(wr))
+    if "TCC_EA0_RDREQ_sum" in tot[k]:
+        # read requests of the L2 to the fabric by size: the byte count needs no correction
+        m = calls[k]["TCC_EA0_RDREQ_sum"]
+        n_all, n32, n64, n128 = (tot[k][c] / m for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum",
+                                                         "TCC_EA0_RDREQ_128B_sum"))
+        rd = 32 * n32 + 64 * n64 + 128 * n128
+        kernels[k].update(read_requests_per_launch=int(n_all), read_requests_32B=int(n32), read_requests_64B=int(n64),
+                          read_requests_128B=int(n128), read_bytes_per_launch=int(rd))
+    if "TCC_EA0_RDREQ_DRAM_sum" in tot[k]:
+        m = calls[k]["TCC_EA0_RDREQ_DRAM_sum"]
+        kernels[k].update(read_requests_dram_per_launch=int(tot[k]["TCC_EA0_RDREQ_DRAM_sum"] / m),
+                          write_requests_per_launch=int(tot[k]["TCC_EA0_WRREQ_sum"] / m),
+                          write_requests_64B_per_launch=int(tot[k]["TCC_EA0_WRREQ_64B_sum"] / m))
+    kernels[k]["hbm_bytes_per_launch"] = int(rd + wr)
 print(json.dumps(dict(workload=workload, command=command,
-                      note="rocprofv3 --pmc, separate passes; FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 "
+                      note="rocprofv3 --pmc, separate passes; read bytes from the request-size split of TCC_EA0_RDREQ when that pass "
+                           "was taken (32/64/128-byte requests), else FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 "
                            "bytes); calibration: k_digest streams 12 B per entry of C once",
                       kernels=kernels), indent=1))

@@ -10,4 +10,5 @@ try:
     print('$name', 'scale $scale', j['value'],'GF', j['ms_per_step'],'ms', 'dense_num',p['dense_num'],'dense_sym',p['dense_sym'],'win',p['window_num'],'light',p['light_num'],'wsym',p['window_sym'],'plan',p['slab_plan'],'bins',p['bins'], 'numfrac', j['phase_totals_rank0']['numeric']['frac_of_hbm_peak'])
 except Exception as e:
     print('$name ERR', e, open('gpurun_out/v_$name.err').read()[-500:])
+    raise SystemExit(1)
 PY
