@@ -1420,10 +1420,14 @@ constexpr int DENSE_COLS = 16384;
 // select below), so the wait for the load is unconditional too: a load whose only use sits in a
 // branch stays "pending" for the compiler on the other path, and the next reuse of its register
 // then drains every outstanding load and store (s_waitcnt vmcnt(0)), prefetches included.
+// Column lc of the window keeps its sum in slot lc ^ ((lc >> 4) & 15): the output pass gives thread t the columns
+// [16t, 16t+16), and without the rotation the lanes of a wave would read their j-th column from the same pair of LDS
+// banks (a stride of 128 bytes); with it the 64 lanes spread over all banks.
+__device__ __forceinline__ unsigned dense_slot(unsigned lc) { return lc ^ ((lc >> 4) & 15u); }
 __device__ __forceinline__ void dense_add(double* acc, uint8_t* flags, int col, int cbase, double v, bool valid = true) {
     const unsigned lc = valid ? (unsigned)(col - cbase) : 0xffffffffu;
     if (lc < (unsigned)DENSE_COLS) {
-        atomicAdd(&acc[lc], v);
+        atomicAdd(&acc[dense_slot(lc)], v);
         flags[lc] = 1;
     }
 }
@@ -1762,7 +1766,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 for (int i = 0; i < 16; i++) {
                     if (__ballot(mm != 0u) == 0ull) break;   // wave-uniform: sparse windows leave after a few steps
                     if (mm) {
-                        const int lc = tid * 16 + __ffs(mm) - 1;
+                        const unsigned lc = dense_slot((unsigned)(tid * 16 + __ffs(mm) - 1));
                         mm &= mm - 1u;
                         vr[i] = acc[lc];
                         acc[lc] = 0.0;
