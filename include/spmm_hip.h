@@ -206,6 +206,13 @@ int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t t
  *      numbers) and stops; this is their consumer: one wave per 8 packed rows. */
 int spmm_spv8_spmv(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x, double* y);
 
+/* ---- Y = A X for nvec right-hand vectors from the same packed formats (HOST pointers): X is ncol x nvec and Y
+ *      nrow x nvec, both row-major, in the ORIGINAL numbering.  The vectors go through in passes of 8, 4, 2 or 1:
+ *      an element of A is loaded once per pass and meets the pass's vectors side by side.  Like spmm_spv8_spmv the
+ *      consumer of serial_newblock_clock.cpp:336-399 and :187-204; nvec = 1 is that call. */
+int spmm_spv8_spmm(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x, int32_t nvec,
+                   double* y);
+
 /* ---- the stages of the pipeline one by one (HOST pointers, caller-allocated outputs).  Each
  *      call uploads its inputs, runs the stage on the GPU and downloads the outputs;
  *      spmm_last_kernel_ms() gives the kernel time of the last call.  Chaining them reproduces

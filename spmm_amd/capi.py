@@ -257,9 +257,8 @@ class Context:
                    keys=a["keys"][:nk].copy(), seq_input=a["seq_input"][:nk].copy())
         return out
 
-    def spv8_spmv(self, T, ncol, x):
-        """y = A x read from the packed formats in T (the dict trace_formats returns); x and y are in the
-        original numbering of the matrix."""
+    @staticmethod
+    def _trace_view(T):
         keep = {k: _np(T[k], F64 if k == "b_data" else I32) for k in
                 ("seq_bitmap", "r_indptr", "bsize_list", "seq_offset", "panel_ptr", "panel_list", "spv8_list", "out_seq_all",
                  "b_indptr", "b_local", "b_data", "keys")}
@@ -268,12 +267,29 @@ class Context:
             setattr(o, k, v.ctypes.data)
         o.bnum, o.n_keys = int(T["bnum"]), int(keep["keys"].size)
         o.n_panel_entries, o.n_spv8 = int(keep["panel_list"].size), int(keep["spv8_list"].size)
+        return o, keep
+
+    def spv8_spmv(self, T, ncol, x):
+        """y = A x read from the packed formats in T (the dict trace_formats returns); x and y are in the
+        original numbering of the matrix."""
+        o, keep = self._trace_view(T)
         nrow, nnz = keep["seq_bitmap"].size, keep["b_local"].size
         x = _np(x, F64)
         assert x.size == ncol
         y = np.empty(nrow, F64)
         _chk(lib().spmm_spv8_spmv(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), C.byref(o), _p(x), _p(y)))
         return y
+
+    def spv8_spmm(self, T, ncol, X):
+        """Y = A X for the columns of X (ncol x nvec, row-major) read from the packed formats in T."""
+        o, keep = self._trace_view(T)
+        nrow, nnz = keep["seq_bitmap"].size, keep["b_local"].size
+        X = np.ascontiguousarray(X, dtype=F64)
+        assert X.ndim == 2 and X.shape[0] == ncol
+        Y = np.empty((nrow, X.shape[1]), F64)
+        _chk(lib().spmm_spv8_spmm(self._h, C.c_int32(nrow), C.c_int32(ncol), C.c_int32(nnz), C.byref(o), _p(X),
+                                  C.c_int32(X.shape[1]), _p(Y)))
+        return Y
 
     # ---- the stages one by one (host arrays) ---------------------------------------
     def bitmap_reorder(self, A, sect=2048):

@@ -1,4 +1,4 @@
-// y = A x straight from the packed per-block formats of the pipeline: the consumer the 8-row
+// y = A x and Y = A X (several right-hand vectors) straight from the packed per-block formats of the pipeline: the consumer the 8-row
 // interleave (serial_newblock_clock.cpp:336-399) and the per-block column numbering (:187-204) are
 // laid out for.  Not present in the reference, which only produces the formats.
 //
@@ -13,10 +13,16 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_gather_x(const double* __restrict__ x, const int32_t* __restrict__ keys, int32_t n,
-                                                  double* __restrict__ xk) {
+// xk[i][v] = X[keys[i]][v0 + v] for the NV vectors of one pass (X row-major with ldx doubles per row)
+template <int NV>
+__global__ void __launch_bounds__(256) k_gather_x(const double* __restrict__ x, int ldx, int v0, const int32_t* __restrict__ keys,
+                                                  int32_t n, double* __restrict__ xk) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) xk[i] = x[keys[i]];
+    if (i < n) {
+        const double* src = x + (int64_t)keys[i] * ldx + v0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) xk[i * NV + v] = src[v];
+    }
 }
 
 __device__ __forceinline__ int upper_bound_i32(const int32_t* a, int n, int v) {   // first index with a[i] > v
@@ -29,14 +35,17 @@ __device__ __forceinline__ int upper_bound_i32(const int32_t* a, int n, int v) {
     return lo;
 }
 
-__global__ void __launch_bounds__(256) k_spv8_spmv(int32_t nunits, int32_t bnum, const int32_t* __restrict__ unit_ptr,
+// NV right-hand vectors per pass: an element of A (value, local column number) is loaded once and meets the NV
+// consecutive values xk[local][0..NV); NV = 1 is the matrix-vector product.
+template <int NV>
+__global__ void __launch_bounds__(256) k_spv8_spmm(int32_t nunits, int32_t bnum, const int32_t* __restrict__ unit_ptr,
                                                    const int32_t* __restrict__ bsize, const int32_t* __restrict__ r_indptr,
                                                    const int32_t* __restrict__ panel_ptr, const int32_t* __restrict__ panel_list,
                                                    const int32_t* __restrict__ spv8_list, const int32_t* __restrict__ out_seq_all,
                                                    const int32_t* __restrict__ seq_bitmap, const int32_t* __restrict__ b_indptr,
                                                    const int32_t* __restrict__ b_local, const double* __restrict__ b_data,
                                                    const int32_t* __restrict__ seq_offset, const double* __restrict__ xk,
-                                                   double* __restrict__ y) {
+                                                   double* __restrict__ y, int ldy, int v0) {
     const int lane = threadIdx.x & 63;
     const int unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (unit >= nunits) return;   // the same for all lanes of a wave
@@ -49,17 +58,27 @@ __global__ void __launch_bounds__(256) k_spv8_spmv(int32_t nunits, int32_t bnum,
     const int npl = panel_ptr[b + 1] - panel_ptr[b];
     const int p = upper_bound_i32(pl, npl, t0) - 1;
     const bool grouped = p + 1 < npl && t0 - pl[p] < spv8_list[panel_ptr[b] - b + p];
-    const double* xb = xk + seq_offset[b];
-    double acc = 0.0;
+    const double* xb = xk + (int64_t)seq_offset[b] * NV;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[v] = 0.0;
+    auto fma_row = [&](double* a, double d, int l) {
+        const double* xr = xb + (int64_t)l * NV;
+#pragma unroll
+        for (int v = 0; v < NV; v++) a[v] += d * xr[v];
+    };
     int t;   // packed row this lane reports
     bool report;
     if (grouped) {
         const int64_t o = base + bip[t0];
         const int total = 8 * (bip[t0 + 1] - bip[t0]);
-        for (int i = lane; i < total; i += 64) acc += b_data[o + i] * xb[b_local[o + i]];
-        acc += __shfl_xor(acc, 8, 64);
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
+        for (int i = lane; i < total; i += 64) fma_row(acc, b_data[o + i], b_local[o + i]);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            acc[v] += __shfl_xor(acc[v], 8, 64);
+            acc[v] += __shfl_xor(acc[v], 16, 64);
+            acc[v] += __shfl_xor(acc[v], 32, 64);
+        }
         t = t0 + lane;
         report = lane < 8;
     } else {
@@ -69,37 +88,52 @@ __global__ void __launch_bounds__(256) k_spv8_spmv(int32_t nunits, int32_t bnum,
             // eight lanes per row
             if (t < rows) {
                 const int64_t s = base + bip[t], e = s + mylen;
-                for (int64_t i = s + (lane & 7); i < e; i += 8) acc += b_data[i] * xb[b_local[i]];
+                for (int64_t i = s + (lane & 7); i < e; i += 8) fma_row(acc, b_data[i], b_local[i]);
             }
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                acc[v] += __shfl_xor(acc[v], 1, 64);
+                acc[v] += __shfl_xor(acc[v], 2, 64);
+                acc[v] += __shfl_xor(acc[v], 4, 64);
+            }
         } else {
             // a long row in the unit: the whole wave on one row after the other, four loads per lane in flight
             for (int c = 0; c < 8 && t0 + c < rows; c++) {
                 const int64_t s = base + bip[t0 + c], e = base + bip[t0 + c + 1];
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                double a0[NV], a1[NV], a2[NV], a3[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) a0[v] = a1[v] = a2[v] = a3[v] = 0.0;
                 int64_t i = s + lane;
                 for (; i + 192 < e; i += 256) {
                     const double d0 = b_data[i], d1 = b_data[i + 64], d2 = b_data[i + 128], d3 = b_data[i + 192];
                     const int l0 = b_local[i], l1 = b_local[i + 64], l2 = b_local[i + 128], l3 = b_local[i + 192];
-                    a0 += d0 * xb[l0]; a1 += d1 * xb[l1]; a2 += d2 * xb[l2]; a3 += d3 * xb[l3];
+                    fma_row(a0, d0, l0); fma_row(a1, d1, l1); fma_row(a2, d2, l2); fma_row(a3, d3, l3);
                 }
-                for (; i < e; i += 64) a0 += b_data[i] * xb[b_local[i]];
-                const double sum = wave_reduce_sum((a0 + a1) + (a2 + a3));
-                if ((lane >> 3) == c) acc = sum;
+                for (; i < e; i += 64) fma_row(a0, b_data[i], b_local[i]);
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const double sum = wave_reduce_sum((a0[v] + a1[v]) + (a2[v] + a3[v]));
+                    if ((lane >> 3) == c) acc[v] = sum;
+                }
             }
         }
         report = (lane & 7) == 0 && t < rows;
     }
-    if (report) y[seq_bitmap[bs + out_seq_all[bs + t]]] = acc;
+    if (report) {
+        double* yr = y + (int64_t)seq_bitmap[bs + out_seq_all[bs + t]] * ldy + v0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) yr[v] = acc[v];
+    }
 }
 
 }  // namespace
 
-extern "C" int spmm_spv8_spmv(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x,
-                              double* y) {
-    ARGCHK(ctx != nullptr && tr != nullptr && nrow >= 0 && ncol >= 0 && nnz >= 0 && (x != nullptr || ncol == 0) && (y != nullptr || nrow == 0));
+namespace {
+int spv8_product(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x, int32_t nvec,
+                 double* y) {
+    ARGCHK(ctx != nullptr && tr != nullptr && nrow >= 0 && ncol >= 0 && nnz >= 0 && nvec >= 1 && (x != nullptr || ncol == 0) &&
+           (y != nullptr || nrow == 0));
+    ARGCHK((int64_t)ncol * nvec < (1ll << 31) && (int64_t)nrow * nvec < (1ll << 31));
     ARGCHK(tr->bnum >= 0 && tr->n_keys >= 0 && tr->n_keys <= nnz);
     ARGCHK(tr->seq_bitmap && tr->r_indptr && tr->bsize_list && tr->seq_offset && tr->panel_ptr && tr->panel_list && tr->spv8_list &&
            tr->out_seq_all && tr->b_indptr && (nnz == 0 || (tr->b_local && tr->b_data && tr->keys)));
@@ -132,9 +166,9 @@ extern "C" int spmm_spv8_spmv(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t
     CHK(ws(ctx, WS_UP6, (size_t)nnz + 1, &d_keys));
     CHK(ws(ctx, WS_MISC5, (size_t)bnum + 1, &d_soff));
     CHK(ws(ctx, WS_UP4, (size_t)nnz + 1, &d_data));
-    CHK(ws(ctx, WS_UP7, (size_t)ncol + 1, &d_x));
-    CHK(ws(ctx, WS_UP8, (size_t)nnz + 1, &d_xk));
-    CHK(ws(ctx, WS_UP9, (size_t)nrow + 1, &d_y));
+    CHK(ws(ctx, WS_UP7, (size_t)ncol * nvec + 1, &d_x));
+    CHK(ws(ctx, WS_UP8, (size_t)nnz * (nvec < 8 ? nvec : 8) + 1, &d_xk));
+    CHK(ws(ctx, WS_UP9, (size_t)nrow * nvec + 1, &d_y));
     hipStream_t st = ctx->stream;
 #define UP(dst, src, count) HIPCHK(hipMemcpyAsync(dst, src, sizeof(*(dst)) * (size_t)(count), hipMemcpyHostToDevice, st))
     UP(d_unit, unit_ptr.data(), bnum + 1);
@@ -152,20 +186,41 @@ extern "C" int spmm_spv8_spmv(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t
         UP(d_data, tr->b_data, nnz);
     }
     if (tr->n_keys) UP(d_keys, tr->keys, tr->n_keys);
-    if (ncol) UP(d_x, x, ncol);
+    if (ncol) UP(d_x, x, (size_t)ncol * nvec);
 #undef UP
     HIPCHK(hipEventRecord(ctx->ev0, st));
-    if (tr->n_keys)
-        hipLaunchKernelGGL(k_gather_x, dim3((unsigned)((tr->n_keys + 255) / 256)), dim3(256), 0, st, d_x, d_keys, tr->n_keys, d_xk);
-    if (nunits)
-        hipLaunchKernelGGL(k_spv8_spmv, dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, nunits, bnum, d_unit, d_bsize, d_rip,
-                           d_pptr, d_plist, d_spv8, d_oseq, d_sbm, d_bip, d_loc, d_data, d_soff, d_xk, d_y);
+    // passes of 8, 4, 2 or 1 right-hand vectors
+    auto pass = [&](auto nv_tag, int v0) {
+        constexpr int NV = decltype(nv_tag)::value;
+        if (tr->n_keys)
+            hipLaunchKernelGGL(k_gather_x<NV>, dim3((unsigned)((tr->n_keys + 255) / 256)), dim3(256), 0, st, d_x, nvec, v0, d_keys,
+                               tr->n_keys, d_xk);
+        if (nunits)
+            hipLaunchKernelGGL(k_spv8_spmm<NV>, dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, nunits, bnum, d_unit, d_bsize,
+                               d_rip, d_pptr, d_plist, d_spv8, d_oseq, d_sbm, d_bip, d_loc, d_data, d_soff, d_xk, d_y, nvec, v0);
+    };
+    int v0 = 0;
+    for (; nvec - v0 >= 8; v0 += 8) pass(std::integral_constant<int, 8>{}, v0);
+    if (nvec - v0 >= 4) { pass(std::integral_constant<int, 4>{}, v0); v0 += 4; }
+    if (nvec - v0 >= 2) { pass(std::integral_constant<int, 2>{}, v0); v0 += 2; }
+    if (nvec - v0 >= 1) pass(std::integral_constant<int, 1>{}, v0);
     HIPCHK(hipEventRecord(ctx->ev1, st));
-    HIPCHK(hipMemcpyAsync(y, d_y, sizeof(double) * (size_t)nrow, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(y, d_y, sizeof(double) * (size_t)nrow * nvec, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->last_ms = ms;
     return SPMM_OK;
+}
+}  // namespace
+
+extern "C" int spmm_spv8_spmv(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x,
+                              double* y) {
+    return spv8_product(ctx, nrow, ncol, nnz, tr, x, 1, y);
+}
+
+extern "C" int spmm_spv8_spmm(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const spmm_trace* tr, const double* x,
+                              int32_t nvec, double* y) {
+    return spv8_product(ctx, nrow, ncol, nnz, tr, x, nvec, y);
 }

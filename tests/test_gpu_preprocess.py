@@ -176,3 +176,28 @@ def test_spmv_over_the_packed_formats(ctx, case):
         assert np.array_equal(orc.spv8_spmv(orc.trace_formats(n, ip, ix, d, threshold=thr), xi), M @ xi)
     xr = rng.standard_normal(n)
     np.testing.assert_allclose(ctx.spv8_spmv(T, n, xr), M @ xr, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("nvec", [1, 2, 3, 8, 13])
+def test_spmm_over_the_packed_formats(ctx, nvec):
+    """Several right-hand vectors at once (passes of 8, 4, 2 and 1): every column of Y = A X equals the matrix-vector
+    product of that column bit for bit (the same sums in the same order), and the CSR product exactly for small
+    integer X."""
+    n, thr = 1 << 11, 300
+    row, col = synth.rmat(11, 8, 21, True)
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    d = np.random.default_rng(4).integers(1, 5, d.size).astype(np.float64)
+    T = ctx.trace_formats(capi.Csr(n, n, ip, ix, d), threshold=thr)
+    import scipy.sparse as sp
+    M = sp.csr_matrix((d, ix, ip), shape=(n, n))
+    rng = np.random.default_rng(5)
+    Xi = rng.integers(1, 9, (n, nvec)).astype(np.float64)
+    Y = ctx.spv8_spmm(T, n, Xi)
+    assert Y.shape == (n, nvec) and np.array_equal(Y, M @ Xi)
+    Xr = rng.standard_normal((n, nvec))
+    Y = ctx.spv8_spmm(T, n, Xr)
+    for v in range(nvec):
+        assert np.array_equal(Y[:, v], ctx.spv8_spmv(T, n, Xr[:, v])), v
+    np.testing.assert_allclose(Y, M @ Xr, rtol=1e-12, atol=1e-12)
+    with pytest.raises(capi.SpmmError):
+        ctx.spv8_spmm(T, n, np.zeros((n, 0)))
