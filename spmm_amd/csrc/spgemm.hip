@@ -975,7 +975,9 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     uint32_t* cs = (uint32_t*)(st_arr + 5 * NW);   // 1024 + 2 entries
     int32_t* wave_ent = (int32_t*)(cs + 1026);       // NW entries: entry (+1) that holds the first product of a wave's slice
     uint16_t* emap = (uint16_t*)pre;                 // U*THREADS entries: product -> entry + 1 (fast windows; pre is free during the sweep)
-    const int gsz = m_min;
+    // adaptive windows grow by single table windows; a window narrower than 32 columns per thread leaves the
+    // threads past its last bitmap word without words of their own
+    const int gsz = (NUMERIC && adaptive) ? 1 : m_min;
     const int nh = (nbase + gsz - 1) / gsz;
     const int gmax = ((WORDS * 32) >> shift) / gsz;
     if (NUMERIC && adaptive) {
@@ -1033,7 +1035,8 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         const int w1 = w1_cur;
         w1_next = w1 < nbase ? window_end(w1) : nbase;
         // bitmap words of this window owned by one thread
-        const int wpt = (NUMERIC && adaptive) ? ((((w1 - w0 + gsz - 1) / gsz * gsz) << shift) >> 5) / THREADS : wpt0;
+        const int nwords = (NUMERIC && adaptive) ? (((w1 - w0 + gsz - 1) / gsz * gsz) << shift) >> 5 : wpt0 * THREADS;
+        const int wpt = (NUMERIC && adaptive) ? (nwords + THREADS - 1) / THREADS : wpt0;
         const int wbase = w0 << shift;
         long long Tw = 0;
         int Tc = 0;
@@ -1210,7 +1213,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < WPT; j++) myw[j] = j < wpt ? bits[tid * wpt + j] : 0u;
+            for (int j = 0; j < WPT; j++) myw[j] = (j < wpt && tid * wpt + j < nwords) ? bits[tid * wpt + j] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < WPT; j++) s += __popc(myw[j]);
@@ -1244,7 +1247,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                 int r = ex;
 #pragma unroll
                 for (int j = 0; j < WPT; j++)
-                    if (j < wpt) { pre[tid * wpt + j] = (pre_t)r; r += __popc(myw[j]); }
+                    if (j < wpt && tid * wpt + j < nwords) { pre[tid * wpt + j] = (pre_t)r; r += __popc(myw[j]); }
             }
         }
         const bool staged = cntw <= VALS;
@@ -1387,7 +1390,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         } else {
 #pragma unroll
             for (int j = 0; j < WPT; j++)
-                if (j < wpt) bits[tid * wpt + j] = 0u;
+                if (j < wpt && tid * wpt + j < nwords) bits[tid * wpt + j] = 0u;
         }
         out += cntw;
         if (NUMERIC && single_chunk && !fast) __syncthreads();   // staged column ids are read before the map is cleared
