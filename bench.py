@@ -226,7 +226,7 @@ def main():
            ("slab_plan", capi.PH_SLAB_PLAN)]}
     ctx.profile(False)
     stamps = None
-    if os.environ.get("SPMM_WIN_STAMPS") == "1":
+    if os.environ.get("SPMM_WIN_STAMPS") in ("1", "2"):
         st = ctx.debug_stamps().astype(np.float64)
         names = ["directory", "sweep_own", "sweep_wait", "prefix", "value_own", "value_wait", "output_rest", "output_vals", "windows", "products"]
         stamps = {k: {n: (round(float(v)) if n in ("windows", "products") else round(float(v) / max(st[o:o + 8].sum(), 1), 3))
@@ -234,6 +234,8 @@ def main():
         for nm, sl in (("sweep", 26), ("value", 27), ("dir", 28), ("postvalue", 29), ("stage", 30)):
             stamps["numeric"][f"skew_{nm}_barrier_cycles_per_window"] = round(float(st[sl] / max(st[24], 1)))
         stamps["numeric"]["cycles_per_window"] = round(float(st[16:24].sum() / max(st[24], 1)))
+        # 1024-thread form only: its register-resident windows (the three skew slots above are then not skews)
+        stamps["numeric"]["fast1024"] = dict(windows=int(st[28]), cycles=int(st[29]), products=int(st[30]))
         stamps["symbolic"]["cycles_per_window"] = round(float(st[0:8].sum() / max(st[8], 1)))
         # the dense kernel uses slots 0..5: sweep, wait for the sweep barrier, flags and sums, wait for the
         # scan barrier, stores, windows

@@ -906,7 +906,7 @@ __device__ __forceinline__ unsigned long long win_clock() {
     }
 
 template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP>
-__global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                  const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12,
                                                  const int32_t* __restrict__ winptr, int nbase, int shift,
@@ -921,11 +921,12 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
     constexpr int dbg = 0;
     (void)dbg_arg;
 #endif
-    // the 256-thread form serves rows of at most 65535 products: ranks fit 16 bits, and two workgroups fit a CU
-    constexpr bool PRE16 = NUMERIC && THREADS == 256;
+    // the 256-thread form serves rows of at most 65535 products, the 512-thread form only runs with adaptive
+    // windows (a window is then one table window of at most 65536 columns or holds at most U*THREADS products):
+    // ranks fit 16 bits, and two workgroups fit a CU
+    constexpr bool PRE16 = NUMERIC && THREADS <= 512;
     using pre_t = typename std::conditional<PRE16, uint16_t, uint32_t>::type;
-    static_assert(!NUMERIC || (size_t)VALS * 4 <= (size_t)WORDS * sizeof(pre_t), "column staging reuses the rank-prefix array");
-    static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
+        static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
     constexpr int WPT = WORDS / THREADS;
     constexpr int NW = THREADS / 64;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1015,13 +1016,15 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         t_hi = T[w1_cur];
         if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
     }
+    unsigned long long win_t0 = 0;
     if (STAMP && tid == 0) {
         for (int i = 0; i < 15; i++) st_lds[i] = 0;
         st_lds[15] = win_clock();
+        win_t0 = st_lds[15];
     }
 #define WIN_ARRIVE(k) if (STAMP && lane == 0) st_arr[(k) * NW + wv] = win_clock();
 #define WIN_SKEW(k, slot)                                                        \
-    if (STAMP && tid == 0) {                                                     \
+    if (STAMP && tid == 0 && (THREADS != 1024 || (slot) < 12)) {                 \
         unsigned long long mn_ = st_arr[(k) * NW], mx_ = mn_;                    \
         for (int i_ = 1; i_ < NW; i_++) {                                        \
             unsigned long long x_ = st_arr[(k) * NW + i_];                       \
@@ -1250,7 +1253,7 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
                     if (j < wpt && tid * wpt + j < nwords) { pre[tid * wpt + j] = (pre_t)r; r += __popc(myw[j]); }
             }
         }
-        const bool staged = cntw <= VALS;
+        const bool staged = cntw <= VALS && (size_t)cntw * 4 <= (size_t)WORDS * sizeof(pre_t);   // column staging reuses the rank-prefix array
         WIN_STAMP(3)   // rank prefix
         for (int r0 = 0; r0 < cntw; r0 += VALS) {
             const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
@@ -1395,6 +1398,11 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
         out += cntw;
         if (NUMERIC && single_chunk && !fast) __syncthreads();   // staged column ids are read before the map is cleared
         WIN_STAMP(6)   // output
+        if (STAMP && THREADS == 1024 && tid == 0) {
+            // register-resident windows of the 1024-thread form: count, cycles (since the previous counted window), products
+            if (fast) { st_lds[12] += 1; st_lds[13] += st_lds[15] - win_t0; st_lds[14] += (unsigned long long)Tw; }
+            win_t0 = st_lds[15];
+        }
         // the next directory build starts with a barrier
     }
     if (STAMP && tid == 0)
@@ -1418,6 +1426,9 @@ __global__ void __launch_bounds__(THREADS) k_win(const int32_t* __restrict__ lis
 // When the table windows are wider than DENSE_COLS the window is swept once per sub-range and
 // products outside the sub-range are skipped.
 constexpr int DENSE_COLS = 16384;
+// sparse runs of the dense kernel: sums and bitmap words that fit the accumulators' LDS (64 + 32 + 32 KiB)
+constexpr int DENSE_SPARSE_VALS = 8192, DENSE_SPARSE_WORDS = 8192;
+static_assert((size_t)DENSE_SPARSE_VALS * 8 + (size_t)DENSE_SPARSE_WORDS * 8 <= (size_t)DENSE_COLS * 8, "sparse-run arrays alias the accumulators");
 
 // `valid` selects lanes that hold a product.  The loaded column is consumed on every path (the
 // select below), so the wait for the load is unconditional too: a load whose only use sits in a
@@ -1553,7 +1564,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    int32_t* __restrict__ c_ix, double* __restrict__ c_val, int dbg_arg,
                                                    unsigned long long* __restrict__ stamps, const int32_t* __restrict__ list_g,
                                                    int n_shared, int ntask_shared, int chunk,
-                                                   const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt, int major_rows) {
+                                                   const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt, int major_rows,
+                                                   int sparse_max) {
     // The first n_shared workgroups work on the rows of list_g, ntask_shared workgroups per row: workgroup
     // t of a row takes the table windows t, t + ntask, ... (in chunks of `chunk`) and finds the place of a
     // window's entries in the row of C from the per-window counts of the symbolic phase (at most THREADS
@@ -1597,10 +1609,10 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     const bool pipelined = cached && nsub == 1;
     int64_t out = c_ip[row] - c_ip[row_beg];
     const int64_t out_row = out;
+    int row_cnt = 0;   // entries of the row of C (shared rows)
     if (ntask > 1) {
         const int v = tid < nbase ? (int)wcnt[(int64_t)gslot[row] * nbase + tid] : 0;
-        int tot;
-        const int ex = block_exclusive_scan<THREADS, int32_t>(v, tmp, &tot);
+        const int ex = block_exclusive_scan<THREADS, int32_t>(v, tmp, &row_cnt);
         pre[tid] = ex;   // visible after the barrier that follows the clearing of the accumulators
     }
 
@@ -1637,6 +1649,90 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
         }
     }
     __syncthreads();
+
+    // ---- sparse runs (window-major workgroups) ---------------------------------------------------
+    // A run of `chunk` table windows that holds at most sparse_max entries of the row of C (known from the
+    // symbolic counts) is handled as ONE bitmap window over chunk * 2^shift columns instead of `chunk` dense
+    // windows of two barriers and an output pass each: an entry's products of the whole run are one segment of
+    // its row of B, so the run costs one (entry, run) pair per entry instead of `chunk`.  Two sweeps over the
+    // products: the first sets one bit per touched column, a rank prefix over the bitmap words follows, the
+    // second adds a*b into vals[rank] and stores the column id at its rank.  The three arrays lie in the
+    // (cleared) dense accumulators; the workgroup ends after its run, so nothing has to be cleared again.
+    if (sparse_max > 0 && major_rows > 0 && shared && nsub == 1) {
+        const int w_end = w_first + chunk < nbase ? w_first + chunk : nbase;
+        const int run_cnt = (w_end < nbase ? pre[w_end] : row_cnt) - pre[w_first];
+        const int nwords = ((w_end - w_first) << shift) >> 5;
+        if (run_cnt <= sparse_max && nwords <= DENSE_SPARSE_WORDS) {
+            if (run_cnt == 0) return;
+            double* vals = acc;                                            // DENSE_SPARSE_VALS sums
+            uint32_t* bits = (uint32_t*)(acc + DENSE_SPARSE_VALS);         // DENSE_SPARSE_WORDS bitmap words
+            uint32_t* spre = bits + DENSE_SPARSE_WORDS;                    // rank prefix per bitmap word
+            const int cbase0 = w_first << shift;
+            const int64_t out_run = out_row + pre[w_first];
+            const int npass_s = (lenA + 64 * NW - 1) / (64 * NW);
+            // one lane per entry, 64 entries per wave and pass; rows of one pass keep their segments in registers
+            int s1 = 0, len1 = 0;
+            double a1 = 0.0;
+            auto entry = [&](int c, int& s_, int& len_, double& a_) {
+                const int e = (c * 64 + lane) * NW + wv;
+                s_ = 0; len_ = 0; a_ = 0.0;
+                if (e < lenA) {
+                    const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                    s_ = Tq[w_first];
+                    len_ = Tq[w_end] - s_;
+                    a_ = a_val[a0 + e];
+                }
+            };
+            if (npass_s == 1) entry(0, s1, len1, a1);
+            for (int c = 0; c < npass_s; c++) {
+                int s_ = s1, len_ = len1;
+                double a_ = a1;
+                if (npass_s > 1) entry(c, s_, len_, a_);
+                if (__ballot(len_ > 0) == 0ull) continue;
+                wave_flat_sweep<true>(nullptr, b12, s_, len_, a_, lane, wmap,
+                                      [&](int col, double, bool valid) {
+                                          const unsigned lc = (unsigned)(col - cbase0);
+                                          atomicOr(&bits[lc >> 5], valid ? 1u << (lc & 31) : 0u);
+                                      },
+                                      [] {});
+            }
+            __syncthreads();
+            const int wpt = (nwords + THREADS - 1) / THREADS;   // a thread owns wpt consecutive bitmap words
+            int cnt_t = 0;
+            for (int j = 0; j < wpt; j++) {
+                const int wd = tid * wpt + j;
+                cnt_t += wd < nwords ? __popc(bits[wd]) : 0;
+            }
+            int cnt_all;
+            int rk0 = block_exclusive_scan<THREADS, int32_t>(cnt_t, tmp, &cnt_all);
+            for (int j = 0; j < wpt; j++) {
+                const int wd = tid * wpt + j;
+                if (wd < nwords) {
+                    spre[wd] = (uint32_t)rk0;
+                    rk0 += __popc(bits[wd]);
+                }
+            }
+            __syncthreads();
+            for (int c = 0; c < npass_s; c++) {
+                int s_ = s1, len_ = len1;
+                double a_ = a1;
+                if (npass_s > 1) entry(c, s_, len_, a_);
+                if (__ballot(len_ > 0) == 0ull) continue;
+                wave_flat_sweep<true>(nullptr, b12, s_, len_, a_, lane, wmap,
+                                      [&](int col, double v, bool valid) {
+                                          // lanes past the end repeat the last product with a zero addend
+                                          const unsigned lc = (unsigned)(col - cbase0);
+                                          const int rk = (int)spre[lc >> 5] + __popc(bits[lc >> 5] & ((1u << (lc & 31)) - 1u));
+                                          atomicAdd(&vals[rk], valid ? v : 0.0);
+                                          c_ix[out_run + rk] = col;
+                                      },
+                                      [] {});
+            }
+            __syncthreads();
+            for (int r = tid; r < cnt_all; r += THREADS) c_val[out_run + r] = vals[r];
+            return;
+        }
+    }
 
     // diagnostic build: cycles of thread 0 per section (0 sweep, 1 wait for the sweep barrier,
     // 2 flags and sums, 3 wait for the scan barrier, 4 stores, 5 windows)
@@ -2018,7 +2114,7 @@ constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + 
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC>
 constexpr size_t win_lds_bytes() {
-    return (NUMERIC ? (size_t)WORDS * (THREADS == 256 ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
+    return (NUMERIC ? (size_t)WORDS * (THREADS <= 512 ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
            (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
            (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0);   // adaptive-window sums (at most 1024 table windows), wave bases
 }
@@ -2295,7 +2391,7 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
-    auto kern = ctx->win_stamps ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
+    auto kern = (ctx->win_stamps == 1 || (ctx->win_stamps == 2 && THREADS == 1024)) ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for_row_slices(ctx, bins.n_w, THREADS, 1, [&](long long off, long long cnt) {
@@ -2330,7 +2426,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
         static_assert(dl <= 160 * 1024, "LDS budget of one CU");
-        auto kd = ctx->win_stamps ? k_dense<1024, true> : k_dense<1024, false>;
+        auto kd = ctx->win_stamps == 1 ? k_dense<1024, true> : k_dense<1024, false>;
         unsigned long long* stamps;
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
@@ -2343,7 +2439,8 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + n_dense)), dim3(1024), dl, ctx->stream, list_w, A->indptr,
                                A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
                                c_val, ctx->win_dbg >> 8, stamps, list_g, n_shared, gtasks, gchunk,
-                               bins.gslot, bins.wcnt, major ? (int)n_g : 0);
+                               bins.gslot, bins.wcnt, major ? (int)n_g : 0,
+                               ctx->dense_sparse < DENSE_SPARSE_VALS ? ctx->dense_sparse : DENSE_SPARSE_VALS);
         };
         const long long max_wg = ctx->max_grid_threads / 1024 > 0 ? ctx->max_grid_threads / 1024 : 1;
         if (bins.n_g * gtasks + bins.n_dense <= max_wg) launch(bins.list_g, bins.n_g, bins.list_w, bins.n_dense);
@@ -2382,7 +2479,13 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             heavy.n_w = bins.n_w - nl;
             light.list_w = bins.list_w + heavy.n_w;
             light.n_w = nl;
-            if (heavy.n_w > 0) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            if (heavy.n_w > 0) {
+                // 512-thread workgroups, two per CU (adaptive windows of a table with 16384-column windows only)
+                if (ctx->win_threads == 512 && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
+                    CHK((launch_win<512, 4096, 4096, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
+                else
+                    CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
+            }
             if (light.n_w > 0) {
                 phase_end(ctx, ph);
                 ph = phase_begin(ctx, SPMM_PH_LIGHT_NUM);

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 # Kernel selections the library reads from the environment when a context is created: the default
 # plan, every window row through the dense-accumulator kernel, the dense kernel off (cursor kernel
 # with 2^15-column table windows), and the cursor kernel for the symbolic phase with fixed-width
-# numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel; every window
+# numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel; dense rows cut into
+# runs of 4 table windows, one workgroup each (runs with few entries of C as one bitmap window: by default up to 8192
+# entries, never, and up to 200 so that both forms meet in one row); every window
 # row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes); no window table of
 # B at all (every window row through the launches over B's slab order), with wide windows and dense accumulators,
 # and with narrow windows, the bitmap-rank accumulators and 256-thread workgroups.
@@ -26,6 +28,8 @@ PLANS = {
     "cursor_sym_fixed_windows": {"SPMM_SYM_CFG": "1", "SPMM_ADAPTIVE": "0"},
     "split_rows": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8", "SPMM_GIANT_MAJOR": "0"},
     "dense_window_major": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4"},
+    "dense_window_major_no_sparse_runs": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_SPARSE": "0"},
+    "dense_window_major_mixed_runs": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_SPARSE": "200"},
     "sliced_launches": {"SPMM_MAX_GRID_THREADS": "8192", "SPMM_DENSE_MIN": "1"},
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: runvar.sh name scale ENV=... ENV=...
 name=$1; scale=$2; shift 2
-env "$@" timeout -k 10 500 python bench.py --scale $scale --steps 1 --warmup 1 --no-cpu > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err
+env "$@" timeout -k 10 ${RUNVAR_TIMEOUT:-500} python bench.py --scale $scale --steps 1 --warmup 1 --no-cpu > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err
 python - <<PY
 import json
 try:
