@@ -905,7 +905,7 @@ __device__ __forceinline__ unsigned long long win_clock() {
         st_lds[15] = now_;                                   \
     }
 
-template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP>
+template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP, bool TWO = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                  const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12,
@@ -976,11 +976,22 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
     uint32_t* cs = (uint32_t*)(st_arr + 5 * NW);   // 1024 + 2 entries
     int32_t* wave_ent = (int32_t*)(cs + 1026);       // NW entries: entry (+1) that holds the first product of a wave's slice
     uint16_t* emap = (uint16_t*)pre;                 // U*THREADS entries: product -> entry + 1 (fast windows; pre is free during the sweep)
+    // Two-level windows (TWO): the bitmap holds one bit per group of 32 columns, so a register-resident window may
+    // span 32 times the columns; every touched group then gets a word of `fine` (its 32 columns), in group order,
+    // and a column's rank is the rank prefix of its fine word plus the bits below it.  Rows of few products in a
+    // wide matrix get windows filled with products instead of windows cut by the bitmap's width.
+    static_assert(!TWO || (NUMERIC && PRE16 && U == 8), "two-level windows: 16-bit ranks, eight products per lane");
+    uint32_t* fine = (uint32_t*)(((uintptr_t)(wave_ent + NW) + 15) & ~(uintptr_t)15);   // TWO: U*THREADS words
+    uint16_t* fpre = (uint16_t*)(fine + U * THREADS);                                    // TWO: rank prefix per fine word
+    if (TWO)
+        for (int i = tid; i < U * THREADS; i += THREADS) fine[i] = 0u;   // ordered before the first use by the barriers of the directory build
     // adaptive windows grow by single table windows; a window narrower than 32 columns per thread leaves the
     // threads past its last bitmap word without words of their own
     const int gsz = (NUMERIC && adaptive) ? 1 : m_min;
     const int nh = (nbase + gsz - 1) / gsz;
     const int gmax = ((WORDS * 32) >> shift) / gsz;
+    // two-level windows of a single-chunk row: up to 32 times as wide (the search below looks at 4 x 64 granules)
+    const int gmax2 = !TWO || !single_chunk ? gmax : ((WORDS * 1024) >> shift) / gsz < 256 ? ((WORDS * 1024) >> shift) / gsz : 256;
     if (NUMERIC && adaptive) {
         for (int j = tid; j <= nh; j += THREADS) cs[j] = 0u;
         __syncthreads();
@@ -1001,6 +1012,20 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
         // the window takes the leading run of lanes whose sum still fits
         const int j0 = w0 / gsz;
         const uint32_t base = cs[j0];
+        if (TWO && gmax2 > 64) {
+            // a window of k granules fits (monotone in k); lanes try 4, 8, .. 256 granules, then three lanes the
+            // granules between the last multiple of 4 that fits and the next
+            auto fit = [&](int k) {
+                const int jk = j0 + k < nh ? j0 + k : nh;
+                return k <= gmax2 && j0 + k <= nh && cs[jk] - base <= (uint32_t)(U * THREADS);
+            };
+            const unsigned long long m1 = __ballot(fit(4 * (lane + 1)));
+            const int c1 = m1 == ~0ull ? 64 : __ffsll(~m1) - 1;
+            const unsigned long long m2 = __ballot(lane < 3 && fit(4 * c1 + 1 + lane));
+            const int c2 = __ffsll(~m2) - 1;
+            const int k = 4 * c1 + c2 > 1 ? 4 * c1 + c2 : 1;
+            return (j0 + k) * gsz < nbase ? (j0 + k) * gsz : nbase;
+        }
         const int jl = j0 + lane + 1 < nh ? j0 + lane + 1 : nh;
         const bool fits = lane >= 1 && lane < gmax && j0 + lane < nh && cs[jl] - base <= (uint32_t)(U * THREADS);
         const unsigned long long m = __ballot(fits) >> 1;          // bit i: the window may grow to 2 + i granules
@@ -1038,8 +1063,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
         const int w1 = w1_cur;
         w1_next = w1 < nbase ? window_end(w1) : nbase;
         // bitmap words of this window owned by one thread
-        const int nwords = (NUMERIC && adaptive) ? (((w1 - w0 + gsz - 1) / gsz * gsz) << shift) >> 5 : wpt0 * THREADS;
-        const int wpt = (NUMERIC && adaptive) ? (nwords + THREADS - 1) / THREADS : wpt0;
+        int nwords = (NUMERIC && adaptive) ? (((w1 - w0 + gsz - 1) / gsz * gsz) << shift) >> 5 : wpt0 * THREADS;
+        int wpt = (NUMERIC && adaptive) ? (nwords + THREADS - 1) / THREADS : wpt0;
         const int wbase = w0 << shift;
         long long Tw = 0;
         int Tc = 0;
@@ -1084,6 +1109,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
             dir[tid] = make_int2(off, s);
             if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
             fast = NUMERIC && single_chunk && Tc <= U * THREADS;
+            if (TWO && fast) {   // the bitmap of a two-level window has one bit per 32 columns
+                nwords = (nwords + 31) >> 5;
+                wpt = (nwords + THREADS - 1) / THREADS;
+            }
             // products per wave: register-resident windows give every wave a fixed slice of U*64
             // products (waves past the end skip the window and issue nothing); the two-sweep form
             // spreads the products evenly, in multiples of 64
@@ -1148,7 +1177,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const bool valid = p_lo + j * 64 + lane < p_hi;
-                    atomicOr(&bits[(cc[j] - wbase) >> 5], valid ? 1u << ((cc[j] - wbase) & 31) : 0u);
+                    const int bit = TWO ? (cc[j] - wbase) >> 5 : cc[j] - wbase;
+                    atomicOr(&bits[bit >> 5], valid ? 1u << (bit & 31) : 0u);
                     pv[j] = valid ? pv[j] * bv[j] : 0.0;
                 }
             } else {
@@ -1255,6 +1285,68 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
         }
         const bool staged = cntw <= VALS && (size_t)cntw * 4 <= (size_t)WORDS * sizeof(pre_t);   // column staging reuses the rank-prefix array
         WIN_STAMP(3)   // rank prefix
+        if constexpr (TWO) {
+            if (fast) {
+                // cntw groups of 32 columns are touched; group g owns fine word rank(g)
+                __syncthreads();   // group ranks complete
+                int fi[U];
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int g = (cc[j] - wbase) >> 5;
+                        fi[j] = (int)pre[g >> 5] + __popc(bits[g >> 5] & ((1u << (g & 31)) - 1u));
+                    }
+                    // lanes past the end of the slice repeat its last product: the same bit again
+#pragma unroll
+                    for (int j = 0; j < U; j++) atomicOr(&fine[fi[j]], 1u << (cc[j] & 31));
+                }
+                __syncthreads();   // fine words complete
+                // rank prefix over the fine words: thread t owns words [U*t, U*t + U)
+                static_assert(U == 8, "two 16-byte reads per thread");
+                const uint4 fa = ((const uint4*)fine)[2 * tid], fb = ((const uint4*)fine)[2 * tid + 1];
+                const uint32_t fw[U] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+                int s2 = 0;
+#pragma unroll
+                for (int j = 0; j < U; j++) s2 += __popc(fw[j]);
+                int ncols;
+                uint32_t r2 = (uint32_t)block_exclusive_scan_1b<THREADS, int32_t>(s2, tmp_pre, &ncols);
+                {
+                    uint32_t h[U];
+#pragma unroll
+                    for (int j = 0; j < U; j++) { h[j] = r2; r2 += __popc(fw[j]); }
+                    ((uint4*)fpre)[tid] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                }
+                __syncthreads();   // column ranks complete
+                WIN_STAMP(3)
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int rk = (int)fpre[fi[j]] + __popc(fine[fi[j]] & ((1u << (cc[j] & 31)) - 1u));
+                        c_ix[out + rk] = cc[j];
+                        cc[j] = rk;
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; j++) atomicAdd(&vals[cc[j]], pv[j]);
+                }
+                WIN_STAMP(4)
+                __syncthreads();   // sums complete, fine words no longer read
+                WIN_STAMP(5)
+                for (int r = tid; r < ncols; r += THREADS) {
+                    c_val[out + r] = vals[r];
+                    vals[r] = 0.0;
+                }
+                if (s2) {
+                    ((uint4*)fine)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+                    ((uint4*)fine)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int j = 0; j < WPT; j++)
+                    if (j < wpt && tid * wpt + j < nwords) bits[tid * wpt + j] = 0u;
+                out += ncols;
+                WIN_STAMP(6)
+                continue;   // the next directory build starts with a barrier
+            }
+        }
         for (int r0 = 0; r0 < cntw; r0 += VALS) {
             const int nsub = cntw - r0 < VALS ? cntw - r0 : VALS;
             if (fast) {
@@ -2112,11 +2204,12 @@ constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16 + 16 * 256;
 
 constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * (8 + 256) + (size_t)threads * 4; }
 
-template <int THREADS, int WORDS, int VALS, bool NUMERIC>
+template <int THREADS, int WORDS, int VALS, bool NUMERIC, bool TWO = false>
 constexpr size_t win_lds_bytes() {
     return (NUMERIC ? (size_t)WORDS * (THREADS <= 512 ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
            (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
-           (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0);   // adaptive-window sums (at most 1024 table windows), wave bases
+           (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0) +  // adaptive-window sums (at most 1024 table windows), wave bases
+           (TWO ? 16 + (size_t)THREADS * 8 * 6 : 0);                               // two-level windows: fine words and their rank prefix
 }
 
 // ---------------------------------------------------------------------------
@@ -2383,16 +2476,16 @@ void for_row_slices(const spmm_ctx* ctx, long long n, int threads, int per_wg, F
     for (long long off = 0; off < n; off += max_rows) f(off, n - off < max_rows ? n - off : max_rows);
 }
 
-template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC>
+template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool TWO = false>
 int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& bins, int32_t* rowcnt,
                const int64_t* c_ip, int32_t row_beg, int32_t* c_ix, double* c_val) {
-    constexpr size_t lds = win_lds_bytes<THREADS, WORDS, VALS, NUMERIC>();
+    constexpr size_t lds = win_lds_bytes<THREADS, WORDS, VALS, NUMERIC, TWO>();
     static_assert(U <= 16, "entry slots are packed two per word and the lane mask has 32 bits");
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
-    auto kern = (ctx->win_stamps == 1 || (ctx->win_stamps == 2 && THREADS == 1024)) ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true>
-                                : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false>;
+    auto kern = (ctx->win_stamps == 1 || (ctx->win_stamps == 2 && THREADS == 1024)) ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true, TWO>
+                                : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false, TWO>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for_row_slices(ctx, bins.n_w, THREADS, 1, [&](long long off, long long cnt) {
         hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(THREADS), lds, ctx->stream, bins.list_w + off, A->indptr,
@@ -2489,7 +2582,11 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             if (light.n_w > 0) {
                 phase_end(ctx, ph);
                 ph = phase_begin(ctx, SPMM_PH_LIGHT_NUM);
-                CHK((launch_win<256, 8192, 2048, 8, 4, NUMERIC>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
+                // two-level windows need the adaptive window search over a table of 16384-column windows
+                if (ctx->light_two && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
+                    CHK((launch_win<256, 4096, 2048, 8, 4, NUMERIC, true>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
+                else
+                    CHK((launch_win<256, 8192, 2048, 8, 4, NUMERIC>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
             }
         }
         else CHK((launch_win<1024, 32768, 0, 8, 8, NUMERIC>(ctx, A, B, bins, rowcnt, c_ip, row_beg, c_ix, c_val)));

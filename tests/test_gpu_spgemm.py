@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 # numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel; dense rows cut into
 # runs of 4 table windows, one workgroup each (runs with few entries of C as one bitmap window: by default up to 8192
 # entries, never, and up to 200 so that both forms meet in one row); every window
-# row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes); no window table of
+# row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes), with two-level
+# windows (a bitmap bit per 32 columns) and with plain ones; no window table of
 # B at all (every window row through the launches over B's slab order), with wide windows and dense accumulators,
 # and with narrow windows, the bitmap-rank accumulators and 256-thread workgroups.
 PLANS = {
@@ -35,6 +36,7 @@ PLANS = {
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
                            "SPMM_SLAB_THREADS": "256"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
+    "small_cursor_workgroups_one_level": {"SPMM_LIGHT_MAX": "65535", "SPMM_LIGHT_TWO": "0"},
 }
 
 
