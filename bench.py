@@ -242,8 +242,8 @@ def main():
         dn = ["sweep", "sweep_wait", "flags_sums", "scan_wait", "stores"]
         stamps["dense"] = {n: round(float(st[i] / max(st[5], 1))) for i, n in enumerate(dn)}
         stamps["dense"]["windows"] = int(st[5])
-        stamps["dense"]["sparse_windows"] = dict(count=int(st[6]), cycles_per_window=round(float(st[7] / max(st[6], 1))))
-        stamps["dense"]["full_windows"] = dict(count=int(st[8]), cycles_per_window=round(float(st[9] / max(st[8], 1))))
+        for nm, sl in (("below_1024", 6), ("below_2048", 8), ("below_4096", 10), ("from_4096", 12)):   # by entries of C
+            stamps["dense"]["windows_" + nm] = dict(count=int(st[sl]), cycles_per_window=round(float(st[sl + 1] / max(st[sl], 1))))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(nnz_c_local)], dtype=torch.float64, device=dev)
     if dist is not None:

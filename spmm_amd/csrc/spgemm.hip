@@ -906,7 +906,7 @@ __device__ __forceinline__ unsigned long long win_clock() {
     }
 
 template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP, bool TWO = false>
-__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : (THREADS == 256 && TWO && WORDS <= 2048) ? 3 : 1) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                  const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12,
                                                  const int32_t* __restrict__ winptr, int nbase, int shift,
@@ -924,7 +924,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
     // the 256-thread form serves rows of at most 65535 products, the 512-thread form only runs with adaptive
     // windows (a window is then one table window of at most 65536 columns or holds at most U*THREADS products):
     // ranks fit 16 bits, and two workgroups fit a CU
-    constexpr bool PRE16 = NUMERIC && THREADS <= 512;
+    constexpr bool PRE16 = NUMERIC && (THREADS <= 512 || TWO);
     using pre_t = typename std::conditional<PRE16, uint16_t, uint32_t>::type;
         static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
     constexpr int WPT = WORDS / THREADS;
@@ -975,7 +975,6 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
     // granule by granule while they hold at most U*THREADS products.
     uint32_t* cs = (uint32_t*)(st_arr + 5 * NW);   // 1024 + 2 entries
     int32_t* wave_ent = (int32_t*)(cs + 1026);       // NW entries: entry (+1) that holds the first product of a wave's slice
-    uint16_t* emap = (uint16_t*)pre;                 // U*THREADS entries: product -> entry + 1 (fast windows; pre is free during the sweep)
     // Two-level windows (TWO): the bitmap holds one bit per group of 32 columns, so a register-resident window may
     // span 32 times the columns; every touched group then gets a word of `fine` (its 32 columns), in group order,
     // and a column's rank is the rank prefix of its fine word plus the bits below it.  Rows of few products in a
@@ -985,6 +984,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
     uint16_t* fpre = (uint16_t*)(fine + U * THREADS);                                    // TWO: rank prefix per fine word
     if (TWO)
         for (int i = tid; i < U * THREADS; i += THREADS) fine[i] = 0u;   // ordered before the first use by the barriers of the directory build
+    // U*THREADS entries: product -> entry + 1 (fast windows); lives in a rank-prefix array, which is free during the sweep
+    uint16_t* emap = TWO ? fpre : (uint16_t*)pre;
     // adaptive windows grow by single table windows; a window narrower than 32 columns per thread leaves the
     // threads past its last bitmap word without words of their own
     const int gsz = (NUMERIC && adaptive) ? 1 : m_min;
@@ -1081,7 +1082,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) k_win(const i
         if (NUMERIC && single_chunk) {
             // product -> entry map of a register-resident window: cleared here, marked after the
             // scan, both ordered by the barriers of the directory build
-            static_assert(!NUMERIC || (U == 8 && 2 * U * THREADS <= WORDS * sizeof(pre_t)), "one 16-byte store per thread clears the map");
+            static_assert(!NUMERIC || (U == 8 && (TWO || 2 * U * THREADS <= WORDS * sizeof(pre_t))), "one 16-byte store per thread clears the map");
             ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
             if (tid < NW) wave_ent[tid] = 0;
         }
@@ -1828,7 +1829,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
 
     // diagnostic build: cycles of thread 0 per section (0 sweep, 1 wait for the sweep barrier,
     // 2 flags and sums, 3 wait for the scan barrier, 4 stores, 5 windows)
-    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_w = 0;   // 6..9: windows with < 1024 / >= 1024 entries of C: count, cycles
+    unsigned long long st[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_w = 0;   // 6..13: windows with < 1024 / < 2048 / < 4096 / more entries of C: count, cycles
     if (STAMP && tid == 0) st_w = st_t = win_clock();
 #define DENSE_STAMP(i) if (STAMP && tid == 0) { const unsigned long long n_ = win_clock(); st[i] += n_ - st_t; st_t = n_; }
     int flip = 0;
@@ -2004,7 +2005,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             DENSE_STAMP(4)
             if (STAMP && tid == 0) {
                 st[5] += 1;
-                const int cls = total < 1024 ? 6 : 8;
+                const int cls = total < 1024 ? 6 : total < 2048 ? 8 : total < 4096 ? 10 : 12;
                 st[cls] += 1;
                 st[cls + 1] += st_t - st_w;
                 st_w = st_t;
@@ -2012,7 +2013,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
         }
     }
     if (STAMP && tid == 0)
-        for (int i = 0; i < 10; i++) atomicAdd(&stamps[i], st[i]);
+        for (int i = 0; i < 14; i++) atomicAdd(&stamps[i], st[i]);
 #undef DENSE_STAMP
 }
 
@@ -2206,7 +2207,7 @@ constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + 
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC, bool TWO = false>
 constexpr size_t win_lds_bytes() {
-    return (NUMERIC ? (size_t)WORDS * (THREADS <= 512 ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
+    return (NUMERIC ? (size_t)WORDS * (THREADS <= 512 || TWO ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
            (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
            (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0) +  // adaptive-window sums (at most 1024 table windows), wave bases
            (TWO ? 16 + (size_t)THREADS * 8 * 6 : 0);                               // two-level windows: fine words and their rank prefix
@@ -2356,10 +2357,10 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     int32_t nr = row_end - row_beg;
     const long long dense_thr = dense_threshold(ctx, out->nbase);
     // Window rows light enough for the 256-thread cursor workgroups (2048 products per register-resident
-    // window, 16 table windows per window at most): 128 products per table window unless set, never more
-    // than 65535 (16-bit ranks).
-    long long light_max = ctx->light_max >= 0 ? ctx->light_max : 128ll * out->nbase;
-    if (light_max > 65535) light_max = 65535;
+    // window): 256 products per table window unless set; with fixed-width windows never more than 65535
+    // (16-bit ranks inside a window).
+    long long light_max = ctx->light_max >= 0 ? ctx->light_max : 256ll * out->nbase;
+    if (light_max > 65535 && !(ctx->adaptive && out->nbase <= 1024 && out->shift <= 14)) light_max = 65535;   // adaptive windows keep every window's ranks below 2^16
     // Numbered rows.  With the table: the symbolic call numbers the dense rows with very many entries, and a numeric
     // call on the same matrices splits them when the symbolic kernel left their per-window counts.  With the slab
     // order: every window row is numbered, by the symbolic call or, failing a matching one, by the numeric call.
@@ -2574,7 +2575,11 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             light.n_w = nl;
             if (heavy.n_w > 0) {
                 // 512-thread workgroups, two per CU (adaptive windows of a table with 16384-column windows only)
-                if (ctx->win_threads == 512 && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
+                if (ctx->win_two && ctx->win_threads == 512 && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
+                    CHK((launch_win<512, 1024, 4096, 8, 4, NUMERIC, true>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
+                else if (ctx->win_two && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
+                    CHK((launch_win<1024, 2048, 8192, 8, 4, NUMERIC, true>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
+                else if (ctx->win_threads == 512 && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
                     CHK((launch_win<512, 4096, 4096, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
                 else
                     CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
@@ -2583,8 +2588,8 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                 phase_end(ctx, ph);
                 ph = phase_begin(ctx, SPMM_PH_LIGHT_NUM);
                 // two-level windows need the adaptive window search over a table of 16384-column windows
-                if (ctx->light_two && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
-                    CHK((launch_win<256, 4096, 2048, 8, 4, NUMERIC, true>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
+                if (ctx->light_two && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)   // 50 KB of LDS: three workgroups per CU
+                    CHK((launch_win<256, 2048, 2048, 8, 4, NUMERIC, true>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
                 else
                     CHK((launch_win<256, 8192, 2048, 8, 4, NUMERIC>(ctx, A, B, light, rowcnt, c_ip, row_beg, c_ix, c_val)));
             }
@@ -2670,8 +2675,8 @@ extern "C" int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* lig
     const int sh = table_shift(b_ncol, ctx->dense_min);
     long long nb = (((int64_t)b_ncol + (1ll << sh) - 1) >> sh);
     if (nb < 1) nb = 1;
-    long long lm = ctx->light_max >= 0 ? ctx->light_max : 128ll * nb;
-    if (lm > 65535) lm = 65535;
+    long long lm = ctx->light_max >= 0 ? ctx->light_max : 256ll * nb;
+    if (lm > 65535 && !(ctx->adaptive && nb <= 1024 && sh <= 14)) lm = 65535;
     if (nb > 1024) lm = 0;
     *light_max_products = lm;
     return SPMM_OK;

@@ -35,6 +35,7 @@ PLANS = {
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
                            "SPMM_SLAB_THREADS": "256"},
+    "cursor_two_level": {"SPMM_WIN_TWO": "1", "SPMM_LIGHT_MAX": "0"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
     "small_cursor_workgroups_one_level": {"SPMM_LIGHT_MAX": "65535", "SPMM_LIGHT_TWO": "0"},
 }
