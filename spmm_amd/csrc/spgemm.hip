@@ -265,14 +265,26 @@ __global__ void __launch_bounds__(256) k_struct_digest(const int32_t* __restrict
         h += mix64((unsigned long long)(uint32_t)s + ((unsigned long long)i + 0x1000000000ull) * 0x9e3779b97f4a7c15ull);
         if (check && i < nrow && s > 0 && s < n_ix && s < ip[i + 1] && ix[s] < ix[s - 1]) descents--;
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_ix; i += stride) {
-        const int c = ix[i];
+    auto column = [&](int64_t i, int c, int before) {
         h += mix64((unsigned long long)(uint32_t)c + ((unsigned long long)i + 0x2000000000ull) * 0x9e3779b97f4a7c15ull);
         if (check) {
             bad |= (uint32_t)c >= (uint32_t)ncol;
-            if (i > 0 && c < ix[i - 1]) descents++;
+            if (c < before) descents++;
         }
+    };
+    // four column ids per 16-byte load where the array allows it (two loads in flight per thread), the rest singly
+    const int64_t n4 = ((uintptr_t)ix & 15) == 0 ? n_ix >> 2 : 0;
+#pragma unroll 2
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+        const int4 c = ((const int4*)ix)[q];
+        const int before = (check && q > 0) ? ix[4 * q - 1] : (int)0x80000000;
+        column(4 * q, c.x, before);
+        column(4 * q + 1, c.y, c.x);
+        column(4 * q + 2, c.z, c.y);
+        column(4 * q + 3, c.w, c.z);
     }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_ix; i += stride)
+        column(i, ix[i], (check && i > 0) ? ix[i - 1] : (int)0x80000000);
     h = wave_reduce_sum(h);
     descents = wave_reduce_sum(descents);
     if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = h; dpart[threadIdx.x >> 6] = descents; }
@@ -1013,7 +1025,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : (THREADS == 256 
         // the window takes the leading run of lanes whose sum still fits
         const int j0 = w0 / gsz;
         const uint32_t base = cs[j0];
-        if (TWO && gmax2 > 64) {
+        if (TWO && gmax2 > gmax) {
             // a window of k granules fits (monotone in k); lanes try 4, 8, .. 256 granules, then three lanes the
             // granules between the last multiple of 4 that fits and the next
             auto fit = [&](int k) {
@@ -2327,7 +2339,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         unsigned long long* dg = (unsigned long long*)counters;
         auto digest = [&](const spmm_csr* M, int slot, int check) {
             int64_t g = ((int64_t)M->nnz + M->nrow + 256) / (256 * 8);
-            if (g > 512) g = 512;
+            if (g > 1024) g = 1024;
             if (g < 1) g = 1;
             hipLaunchKernelGGL(k_struct_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, M->indptr, M->nrow, M->indices,
                                (int64_t)M->nnz, dg + slot, check, M->ncol, counters);
