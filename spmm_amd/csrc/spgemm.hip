@@ -9,18 +9,24 @@
 //                            workgroup has the gather chains of eight rows in flight
 //   P_i <= ESC_S_CAP (512)   k_esc: one 64-lane workgroup expands the products into LDS, bitonic
 //                            sort by column, runs of equal columns summed
-//   P_i <= ESC_R_CAP (8192)  k_escr: expand (column, index) pairs, stable LSD radix sort in LDS,
+//   P_i <= 4096 (SPMM_ESC_MAX, at most ESC_R_CAP = 8192)
+//                            k_escr: expand (column, index) pairs, stable LSD radix sort in LDS,
 //                            runs summed in product order; independent of the column span
-//   larger                   "window" rows, one 1024-thread workgroup per row, heaviest first,
-//                            over the window-pointer table of B (k_winptr): T[k][w] = first
-//                            position of B row k with column >= w << shift, so the part of a B
-//                            row inside a column window costs two loads and no search.
+//   larger                   "window" rows, one workgroup per row, heaviest first, over the
+//                            window-pointer table of B (k_winptr): T[k][w] = first position of B
+//                            row k with column >= w << shift, so the part of a B row inside a
+//                            column window costs two loads and no search.
 //       symbolic             k_symd: LDS bitmap of 2^20 columns, one ds_or per product
 //       numeric, P_i >= dense threshold (3072 products per table window)
-//                            k_dense: dense fp64 accumulators for 2^14 columns + flag bytes
-//       numeric, below       k_win: bitmap + popcount rank prefix + compact fp64 accumulators
-//                            per window of up to 2^18 columns; windows of at most 8192 products
-//                            stay in registers between the bit sweep and the value phase
+//                            k_dense: dense fp64 accumulators for 2^14 columns + flag bytes; a run
+//                            of 8 table windows with at most 8192 entries of C as one bitmap window
+//       numeric, below       k_win, 1024 threads: bitmap + popcount rank prefix + compact fp64
+//                            accumulators per window of up to 2^18 columns; windows of at most
+//                            8192 products stay in registers between the bit sweep and the values
+//       numeric, P_i <= 256 products per table window
+//                            k_win, 256 threads, three workgroups per CU, two-level windows: a bitmap
+//                            bit per 32 columns and a word per touched group, so a window is cut by
+//                            its 2048 products and not by the bitmap's width
 //   The output rows are sorted by column in every bin; global-memory accumulation is never used.
 #include "common.h"
 
@@ -34,7 +40,14 @@ constexpr int ESC_S_CAP = 512;
 #define ESC_T_LANES 8      // this many lanes each (8 x 64 measured best on web-sized graphs; 16 x 64: +5 %, 16 x 128: +10 %)
 #endif
 constexpr int ESC_L_CAP = 4096;
+constexpr int ESC_MAX_DEFAULT = 4096;   // measured at R-MAT-22: 8192 -> 4096 saves 17 ms of numeric and costs 9 ms of symbolic; lower limits cost more symbolic time than they save
 constexpr int ESC_R_CAP = 8192;         // radix expand-sort-compress: rows with up to this many products and 65535 entries
+// Rows above this many products take the window kernels (at most ESC_R_CAP, at least ESC_S_CAP; SPMM_ESC_MAX sets it).
+static int esc_max_products() {
+    const char* e = getenv("SPMM_ESC_MAX");
+    const int x = e ? atoi(e) : ESC_MAX_DEFAULT;
+    return x < ESC_S_CAP ? ESC_S_CAP : x > ESC_R_CAP ? ESC_R_CAP : x;
+}
 constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14 .. 2^17 columns
 constexpr int WIN_SHIFT_MAX = 17;
 constexpr int KEY_PAD = 0x7fffffff;
@@ -144,7 +157,7 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
                                                           int32_t* __restrict__ list_s, int32_t s_top,
                                                           int32_t* __restrict__ list_l, int32_t* __restrict__ list_m,
                                                           int32_t* __restrict__ list_w, uint32_t* __restrict__ key_w,
-                                                          long long dense_thr, long long light_max, int giant_mode, int giant_len,
+                                                          long long dense_thr, long long light_max, int esc_max, int giant_mode, int giant_len,
                                                           int32_t* __restrict__ gslot, int32_t* __restrict__ list_g,
                                                           int slab, int32_t* __restrict__ slot_row, uint32_t* __restrict__ key_g,
                                                           long long* __restrict__ counters) {
@@ -166,7 +179,7 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
         // Dense rows with very many entries are a long serial chain for one workgroup.  The symbolic call
         // (giant_mode 1) numbers them; a numeric call that can use the symbolic call's per-window counts
         // (giant_mode 2) takes them out of the window list and splits each over several workgroups.
-        const bool is_win = p > ESC_R_CAP || (p > ESC_S_CAP && many_entries);   // the row takes the window kernels
+        const bool is_win = p > esc_max || (p > ESC_S_CAP && many_entries);   // the row takes the window kernels
         // Without the window table of B (slab != 0) every window row takes the launches over B's slab order: the
         // symbolic call numbers them all (giant_mode 1) and later calls on the same matrices keep the numbers.
         // giant_mode 2 reads the numbers of the symbolic call; the other modes leave -1 for the rows they do not number
@@ -179,7 +192,7 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
         else if (giant_mode != 2) gslot[row] = -1;
         if (slab && is_win) cat = C_G;
         else if (giant_mode == 2 && p >= dense_thr && gslot[row] >= 0) cat = C_G;
-        else if (p > ESC_L_CAP && p <= ESC_R_CAP && !many_entries) cat = C_M;
+        else if (p > ESC_L_CAP && p <= esc_max && !many_entries) cat = C_M;
         else if (is_win) {
             cat = C_W;
             dense = p >= dense_thr;
@@ -2390,7 +2403,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     if (!reuse) {
         if (nr > 0)
             hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
-                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, giant_mode,
+                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, esc_max_products(), giant_mode,
                                major ? 0 : ctx->giant_len, out->gslot, list_g0, (slab && mode != BINS_PRODUCTS) ? 1 : 0, out->slot_row, key_g0, counters);
         HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2696,7 +2709,7 @@ extern "C" int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* lig
 
 extern "C" void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large) {
     if (esc_small) *esc_small = ESC_S_CAP;
-    if (esc_large) *esc_large = ESC_R_CAP;
+    if (esc_large) *esc_large = esc_max_products();
 }
 
 extern "C" int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* prod, int64_t* total) {
