@@ -156,9 +156,9 @@ def main():
     P_total = ctx.row_products_dev(vB, vB, prod)
     # rows of A per rank: equal shares of the intermediate products, weighted by the kernel class of the row
     _, esc_max = capi.bin_limits()
-    _, _, dense_min_products = ctx.plan_info(n)
+    _, table_windows, dense_min_products = ctx.plan_info(n)
     bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min_products, max(ctx.light_max(n), esc_max),
-                                        indptr[1:] - indptr[:-1])
+                                        indptr[1:] - indptr[:-1], table_windows)
     r_lo, r_hi = bounds[rank], bounds[rank + 1]
     rows_l = r_hi - r_lo
     P_local = int(prod[r_lo:r_hi].sum())

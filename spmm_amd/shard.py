@@ -63,25 +63,26 @@ def product_balanced_bounds(prod, world):
 
 # Cost model of a row shard, in ns per intermediate product and ns per row by the kernel class of the row, fitted
 # to the times (symbolic + numeric, one MI355X, R-MAT scale 22) of the rows of every range of products taken as a
-# matrix of their own (tools/class_cost.py).  The sorted rows are dear per product, the cursor rows per row (a row
-# pays for its column windows whatever its products).  A dense row pays per entry of its row of A as well (the
-# bounds of the window table it reads for the entry): 8.9 ns per entry next to 3.2 ps per product when the row
-# lengths are given, a quarter more for the rows of more than 8192 entries that several workgroups share (balance
-# over 8 shards: 0.97 at scale 22, 0.99 at scale 21, 0.85 at scale 20, where a shard is a 21 ms step); 8.2 ps per
-# product stands for both when they are not.  Only the ratios matter.
-COST_NS = {"dense": 0.0082, "window": 0.0075, "light": 0.0072, "sorted": 0.0272}
-ROW_NS = {"dense": 0.0, "window": 175.0, "light": 212.0, "sorted": 3.2}
-DENSE_WITH_LENS_NS = 0.0032
-DENSE_ENTRY_NS = 8.9
+# matrix of their own (tools/class_cost.py).  The sorted rows are dear per product, the cursor rows per row.  A
+# dense row pays per entry of its row of A as well (the bounds of the window table it reads for the entry): 7.2 ns
+# per entry next to 2.6 ps per product when the row lengths are given, a quarter more for the rows of more than
+# 8192 entries that several workgroups share; 6.5 ps per product stands for both when they are not.  Only the
+# ratios matter.
+COST_NS = {"dense": 0.0065, "window": 0.00755, "light": 0.0091, "sorted": 0.0239}
+ROW_NS = {"dense": 0.0, "window": 125.0, "light": 62.0, "sorted": 6.6}
+DENSE_WITH_LENS_NS = 0.0026
+DENSE_ENTRY_NS = 7.2
+DENSE_ENTRY_WINDOW_POWER = 0.55   # measured: 8 shards at scale 24 (1024 windows) balance at 2.1 times the cost per entry of 256 windows
 GIANT_ENTRIES = 8192      # rows of A above this are shared by several workgroups, each walking the whole table row
 GIANT_FACTOR = 1.25
 ANY_ROW_NS = 1.0          # row products and classification, paid by empty rows too
 
 
-def row_costs(prod, sorted_max, dense_min, light_max=None, lens=None):
+def row_costs(prod, sorted_max, dense_min, light_max=None, lens=None, windows=256):
     """Modelled cost (ns) of every row: rows with at most sorted_max products are sorted, rows with at least
     dense_min use dense accumulators, the rows between are cursor rows (the small workgroups up to light_max).
-    lens: entries per row of A (optional)."""
+    lens: entries per row of A (optional); windows: table windows of B (a dense row reads the bounds of every window
+    for every entry, runs of sparse windows excepted, so its cost per entry grows with them; fitted at 256)."""
     p = prod.to(torch.float64)
     w = torch.full_like(p, COST_NS["window"])
     r = torch.full_like(p, ROW_NS["window"])
@@ -95,17 +96,17 @@ def row_costs(prod, sorted_max, dense_min, light_max=None, lens=None):
     if lens is not None:
         g = torch.where(lens > GIANT_ENTRIES, GIANT_FACTOR, 1.0).to(torch.float64)
         w[m] = DENSE_WITH_LENS_NS * g[m]
-        r[m] = lens.to(torch.float64)[m] * DENSE_ENTRY_NS * g[m]
+        r[m] = lens.to(torch.float64)[m] * (DENSE_ENTRY_NS * (max(int(windows), 1) / 256.0) ** DENSE_ENTRY_WINDOW_POWER) * g[m]
     return p * w + r * (prod > 0).to(torch.float64) + ANY_ROW_NS
 
 
-def cost_balanced_bounds(prod, world, sorted_max, dense_min, light_max=None, lens=None):
+def cost_balanced_bounds(prod, world, sorted_max, dense_min, light_max=None, lens=None, windows=256):
     """Row boundaries like product_balanced_bounds, with every row weighted by the modelled cost of its kernel
     class (row_costs), so that the ranks finish together and not merely hold the same number of products."""
     n = prod.numel()
     if n == 0:
         return [0] * (world + 1)
-    cum = torch.cumsum(row_costs(prod, sorted_max, dense_min, light_max, lens), 0)
+    cum = torch.cumsum(row_costs(prod, sorted_max, dense_min, light_max, lens, windows), 0)
     total = float(cum[-1])
     bounds = [0]
     for r in range(1, world):

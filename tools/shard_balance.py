@@ -31,9 +31,9 @@ def main():
     prod = torch.empty(n, dtype=torch.int64, device=dev)
     P_total = ctx.row_products_dev(vB, vB, prod)
     _, esc_max = capi.bin_limits()
-    _, _, dense_min = ctx.plan_info(n)
+    _, table_windows, dense_min = ctx.plan_info(n)
     bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min, max(ctx.light_max(n), esc_max),
-                                        indptr[1:] - indptr[:-1])
+                                        indptr[1:] - indptr[:-1], table_windows)
     cap = int(96 * (1 << 30) / 12)
     c_ix = torch.empty(cap, dtype=torch.int32, device=dev)
     c_val = torch.empty(cap, dtype=torch.float64, device=dev)
