@@ -2226,6 +2226,256 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
     if (tid == 0) rowcnt[row] = tmp[0];
 }
 
+// ---------------------------------------------------------------------------
+// Symbolic phase of the light window rows: 256-thread workgroups of 33 KB, four per CU, with the two-level windows of
+// the numeric light kernel.  A row of few products in a wide matrix costs k_symd a fixed price per 2^20 columns
+// (a pass over all entries and a count over the 128 KB bitmap); here a window is cut by its S2_CAP products: the
+// products go to registers and set one bit per group of 32 columns, every touched group gets a word of `fine` in
+// group order (rank prefix over the group bitmap), the products set their column's bit there, and the row's count
+// is the number of bits in the fine words.  A window that the products of one table window overfill, and every
+// window of a row with more than 256 entries, uses `fine` as a plain bitmap over at most 2^16 columns and reads
+// its products through the directory cursor instead.
+constexpr int S2_THREADS = 256, S2_WORDS = 2048, S2_U = 8, S2_CAP = S2_U * S2_THREADS;
+__global__ void __launch_bounds__(S2_THREADS, 4) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                        const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
+                                                        const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                        int32_t* __restrict__ rowcnt) {
+    constexpr int THREADS = S2_THREADS, NW = THREADS / 64, U = S2_U;
+    static_assert(U == 8, "eight 16-bit marks and eight fine words per thread move as 16-byte pieces");
+    __shared__ __align__(16) uint32_t coarse[S2_WORDS];
+    __shared__ __align__(16) uint16_t cpre[S2_WORDS];
+    __shared__ __align__(16) uint32_t fine[S2_CAP];
+    __shared__ __align__(16) uint16_t emap[S2_CAP];
+    __shared__ int2 dirs[2][THREADS + 1];
+    __shared__ uint32_t cs[1026];
+    __shared__ int32_t tmp_a[NW + 1], tmp_b[NW + 1], tmp_c[NW + 1], wave_ent[NW], total_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    const bool single = lenA <= THREADS;
+    for (int i = tid; i < S2_WORDS; i += THREADS) coarse[i] = 0u;
+    for (int i = tid; i < S2_CAP; i += THREADS) fine[i] = 0u;
+    if (tid == 0) total_cnt = 0;
+    // cs[j] = sum over the row's entries of the table value at window j: the products of a range of table windows
+    // are a difference of two of them
+    for (int j = tid; j <= nbase; j += THREADS) cs[j] = 0u;
+    __syncthreads();
+    for (int jb = 0; jb <= nbase; jb += 64) {
+        const int j = jb + lane;
+        uint32_t sum = 0;
+        if (j <= nbase)
+            for (int e = wv; e < lenA; e += NW) sum += (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + j];
+        if (j <= nbase && sum) atomicAdd(&cs[j], sum);
+    }
+    __syncthreads();
+    // widest window in table windows: two-level windows of a single-chunk row, plain windows in `fine` otherwise
+    const int g2 = (S2_WORDS * 1024) >> shift;
+    const int gmax = single ? (g2 < 256 ? g2 : 256) : ((S2_CAP * 32) >> shift);
+    auto window_end = [&](int w0) {
+        // a window of k table windows fits (monotone in k): lanes try 4, 8, .. 256, then three lanes the ones between
+        const uint32_t base = cs[w0];
+        auto fit = [&](int k) {
+            const int jk = w0 + k < nbase ? w0 + k : nbase;
+            return k <= gmax && w0 + k <= nbase && cs[jk] - base <= (uint32_t)S2_CAP;
+        };
+        const unsigned long long m1 = __ballot(fit(4 * (lane + 1)));
+        const int c1 = m1 == ~0ull ? 64 : __ffsll(~m1) - 1;
+        const unsigned long long m2 = __ballot(lane < 3 && fit(4 * c1 + 1 + lane));
+        const int c2 = __ffsll(~m2) - 1;
+        const int k = 4 * c1 + c2 > 1 ? 4 * c1 + c2 : 1;
+        return w0 + k < nbase ? w0 + k : nbase;
+    };
+    int w1_cur = window_end(0), w1_next = 0;
+    const int32_t* T = winptr;
+    int t_lo = 0, t_hi = 0;
+    if (single && tid < lenA) {
+        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
+        t_lo = T[0];
+        t_hi = T[w1_cur];
+    }
+    int mycount = 0, flip = 0;
+    for (int w0 = 0; w0 < nbase; w0 = w1_cur, w1_cur = w1_next) {
+        const int w1 = w1_cur;
+        w1_next = w1 < nbase ? window_end(w1) : nbase;
+        const uint32_t prod_w = cs[w1] - cs[w0];
+        // this entry's part of the window (single-chunk rows); the bound of the next window is loaded a window ahead
+        int s = 0, len = 0;
+        if (single && tid < lenA) {
+            s = t_lo;
+            len = t_hi - t_lo;
+            t_lo = t_hi;
+            if (w1 < nbase) t_hi = T[w1_next];
+        }
+        if (prod_w == 0u) continue;   // block-uniform
+        const int wbase = w0 << shift;
+        if (single && prod_w <= (uint32_t)S2_CAP) {
+            // ---- two-level window, products in registers ------------------------------------------------------
+            // the directory alternates between two buffers, so its build needs no barrier in front
+            flip ^= 1;
+            int2* dir = dirs[flip];
+            ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < NW) wave_ent[tid] = 0;
+            int Tc;
+            const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
+            dir[tid] = make_int2(off, s);
+            if (len > 0) {
+                // where this entry's products start, and the 512-product slices that start inside it
+                emap[off] = (uint16_t)(tid + 1);
+                for (int b = off / (U * 64) + 1; b * (U * 64) < off + len; b++) wave_ent[b] = tid + 1;
+            }
+            __syncthreads();
+            const int p_lo = wv * (U * 64);
+            const int p_hi = p_lo + U * 64 < Tc ? p_lo + U * 64 : Tc;
+            const bool active = p_lo < p_hi;   // wave-uniform
+            int cc[U];
+            if (active) {
+                // running maximum of the marks over the slice = entry (+1) of every product
+                uint4* mine = (uint4*)(emap + p_lo + lane * U);
+                const uint4 raw = *mine;
+                int v[U] = {(int)(raw.x & 0xffffu), (int)(raw.x >> 16), (int)(raw.y & 0xffffu), (int)(raw.y >> 16),
+                            (int)(raw.z & 0xffffu), (int)(raw.z >> 16), (int)(raw.w & 0xffffu), (int)(raw.w >> 16)};
+#pragma unroll
+                for (int i = 1; i < U; i++) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
+                const int inc = wave_inclusive_max_nonneg(v[U - 1]);
+                int before = dpp_shr1(inc);
+                const int wb = wave_ent[wv];
+                before = (lane != 0 && before > wb) ? before : wb;
+#pragma unroll
+                for (int i = 0; i < U; i++) v[i] = v[i] > before ? v[i] : before;
+                *mine = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                   (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+                wave_sync_lds();   // the other lanes of the wave read these entries next
+                int pos[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int p = p_lo + j * 64 + lane;
+                    const int pc = p < p_hi ? p : p_hi - 1;   // lanes past the end repeat the slice's last product
+                    const int2 d = dir[(int)emap[pc] - 1];
+                    pos[j] = d.y + (pc - d.x);
+                }
+#pragma unroll
+                for (int j = 0; j < U; j++) cc[j] = b_ix[pos[j]] - wbase;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int g = cc[j] >> 5;
+                    atomicOr(&coarse[g >> 5], 1u << (g & 31));
+                }
+            }
+            __syncthreads();
+            // rank prefix over the group bitmap: thread t owns words [wpt*t, wpt*t + wpt)
+            const int nwords = (((w1 - w0) << shift) + 1023) >> 10;
+            const int wpt = (nwords + THREADS - 1) / THREADS;
+            int sc = 0;
+            for (int j = 0; j < wpt; j++) {
+                const int wd = tid * wpt + j;
+                sc += wd < nwords ? __popc(coarse[wd]) : 0;
+            }
+            int ngroups;
+            int r1 = block_exclusive_scan_1b<THREADS, int32_t>(sc, tmp_b, &ngroups);
+            for (int j = 0; j < wpt; j++) {
+                const int wd = tid * wpt + j;
+                if (wd < nwords) {
+                    cpre[wd] = (uint16_t)r1;
+                    r1 += __popc(coarse[wd]);
+                }
+            }
+            __syncthreads();
+            if (active) {
+                int fi[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int g = cc[j] >> 5;
+                    fi[j] = (int)cpre[g >> 5] + __popc(coarse[g >> 5] & ((1u << (g & 31)) - 1u));
+                }
+#pragma unroll
+                for (int j = 0; j < U; j++) atomicOr(&fine[fi[j]], 1u << (cc[j] & 31));
+            }
+            __syncthreads();
+            // count and clear: thread t owns fine words [8t, 8t + 8) and its words of the group bitmap
+            {
+                const uint4 fa = ((const uint4*)fine)[2 * tid], fb = ((const uint4*)fine)[2 * tid + 1];
+                const int c = __popc(fa.x) + __popc(fa.y) + __popc(fa.z) + __popc(fa.w) + __popc(fb.x) + __popc(fb.y) +
+                              __popc(fb.z) + __popc(fb.w);
+                if (c) {
+                    ((uint4*)fine)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+                    ((uint4*)fine)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                mycount += c;
+                for (int j = 0; j < wpt; j++) {
+                    const int wd = tid * wpt + j;
+                    if (wd < nwords) coarse[wd] = 0u;
+                }
+            }
+            // the next window's first writes to these arrays follow the barriers of its directory build
+        } else {
+            // ---- plain bitmap of the window in `fine`, products through the directory cursor --------------------
+            int2* dir = dirs[0];
+            for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+                __syncthreads();   // earlier readers of the directory, and the clearing of the window before
+                if (!single) {
+                    const int e = c0 + tid;
+                    s = 0;
+                    len = 0;
+                    if (e < lenA) {
+                        const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                        s = Tp[w0];
+                        len = Tp[w1] - s;
+                    }
+                }
+                int Tc;
+                const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp_c, &Tc);
+                dir[tid] = make_int2(off, s);
+                if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
+                __syncthreads();
+                if (Tc == 0) continue;
+                const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+                const int p_lo = wv * per;
+                const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+                if (p_lo >= p_hi) continue;   // wave-uniform
+                WinCursor<THREADS> cur;
+                cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
+                for (int pb = p_lo; pb < p_hi; pb += 64 * 4) {
+                    int pos[4];
+                    unsigned ok = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int p = pb + j * 64 + lane;
+                        pos[j] = 0;
+                        if (p < p_hi) {
+                            ok |= 1u << j;
+                            cur.seek(dir, p);
+                            pos[j] = cur.start + (p - cur.off);
+                        }
+                    }
+                    int c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) c[j] = b_ix[pos[j]];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (ok & (1u << j)) atomicOr(&fine[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
+                }
+            }
+            __syncthreads();
+            {
+                const uint4 fa = ((const uint4*)fine)[2 * tid], fb = ((const uint4*)fine)[2 * tid + 1];
+                const int c = __popc(fa.x) + __popc(fa.y) + __popc(fa.z) + __popc(fa.w) + __popc(fb.x) + __popc(fb.y) +
+                              __popc(fb.z) + __popc(fb.w);
+                if (c) {
+                    ((uint4*)fine)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+                    ((uint4*)fine)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                mycount += c;
+            }
+        }
+    }
+    mycount = wave_reduce_sum(mycount);
+    if (lane == 0 && mycount) atomicAdd(&total_cnt, mycount);
+    __syncthreads();
+    if (tid == 0) rowcnt[row] = total_cnt;
+}
+
 constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16 + 16 * 256; }
 
 constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + (size_t)(threads / 64) * (8 + 256) + (size_t)threads * 4; }
@@ -2580,9 +2830,15 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         static_assert(sl <= 160 * 1024, "LDS budget of one CU");
         auto ks = k_symd<1024>;
         HIPCHK(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
-        for_row_slices(ctx, bins.n_w, 1024, 1, [&](long long off, long long cnt) {
+        // light rows (the tail of the heaviest-first list) take the small two-level workgroups
+        long long nl = (ctx->light_sym && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14) ? (bins.n_light < bins.n_w ? bins.n_light : bins.n_w) : 0;
+        for_row_slices(ctx, bins.n_w - nl, 1024, 1, [&](long long off, long long cnt) {
             hipLaunchKernelGGL(ks, dim3((unsigned)cnt), dim3(1024), sl, ctx->stream, bins.list_w + off, A->indptr, A->indices,
                                B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt, bins.gslot, bins.wcnt);
+        });
+        for_row_slices(ctx, nl, S2_THREADS, 1, [&](long long off, long long cnt) {
+            hipLaunchKernelGGL(k_sym2, dim3((unsigned)cnt), dim3(S2_THREADS), 0, ctx->stream, bins.list_w + (bins.n_w - nl) + off,
+                               A->indptr, A->indices, B->indices, bins.winptr, bins.nbase, bins.shift, rowcnt);
         });
         ctx->plan.has_wcnt = bins.wcnt != nullptr;   // the numeric call may now split the numbered rows
         phase_end(ctx, phs);
