@@ -97,8 +97,6 @@ struct spmm_ctx {
     int dense_sparse = 8192;  // runs of table windows of a dense row with at most this many entries of C are one bitmap window (0 = off)
     int light_two = 1;        // light window rows: two-level windows (a bitmap bit per 32 columns, then a word per touched group)
     int light_sym = 1;        // symbolic phase of the light window rows on the small two-level workgroups (k_sym2) instead of k_symd
-    int win_two = 0;          // the 1024-thread cursor workgroups with two-level windows
-    int win_threads = 1024;   // workgroup size of the cursor kernel for the rows above the light ones (1024, or 512: two per CU)
     int win_stamps = 0;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int adaptive = 1;       // numeric k_win: window widths follow the row's product distribution
     int sym_cfg = 0;        // symbolic window kernel: 0 = k_symd (tiered sweep), 1 = k_win

@@ -61,8 +61,6 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     if (const char* e = getenv("SPMM_DENSE_SPARSE")) c->dense_sparse = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("SPMM_LIGHT_TWO")) c->light_two = atoi(e);
     if (const char* e = getenv("SPMM_LIGHT_SYM")) c->light_sym = atoi(e);
-    if (const char* e = getenv("SPMM_WIN_TWO")) c->win_two = atoi(e);
-    if (const char* e = getenv("SPMM_WIN_THREADS")) c->win_threads = atoi(e) == 512 ? 512 : 1024;
 #ifdef SPMM_DIAG
     if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);   // diagnostic builds only: results are wrong when nonzero
 #endif

@@ -931,7 +931,7 @@ __device__ __forceinline__ unsigned long long win_clock() {
     }
 
 template <int THREADS, int WORDS, int VALS, int U, int UG, bool NUMERIC, bool STAMP, bool TWO = false>
-__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : (THREADS == 256 && TWO && WORDS <= 2048) ? 3 : 1) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+__global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 2048) ? 3 : 1) k_win(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                  const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12,
                                                  const int32_t* __restrict__ winptr, int nbase, int shift,
@@ -946,10 +946,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : (THREADS == 256 
     constexpr int dbg = 0;
     (void)dbg_arg;
 #endif
-    // the 256-thread form serves rows of at most 65535 products, the 512-thread form only runs with adaptive
-    // windows (a window is then one table window of at most 65536 columns or holds at most U*THREADS products):
-    // ranks fit 16 bits, and two workgroups fit a CU
-    constexpr bool PRE16 = NUMERIC && (THREADS <= 512 || TWO);
+    // the 256-thread forms serve rows of at most 65535 products or run with adaptive windows only (a window is then
+    // one table window of at most 65536 columns or holds at most U*THREADS products): ranks fit 16 bits
+    constexpr bool PRE16 = NUMERIC && (THREADS <= 256 || TWO);
     using pre_t = typename std::conditional<PRE16, uint16_t, uint32_t>::type;
         static_assert(!NUMERIC || U * THREADS <= VALS, "a register-resident window must fit the accumulators");
     constexpr int WPT = WORDS / THREADS;
@@ -1776,6 +1775,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     // products: the first sets one bit per touched column, a rank prefix over the bitmap words follows, the
     // second adds a*b into vals[rank] and stores the column id at its rank.  The three arrays lie in the
     // (cleared) dense accumulators; the workgroup ends after its run, so nothing has to be cleared again.
+    // (Measured and not kept: runs above the limit covered by two to eight such windows, each within the limit: at
+    // more than about 1024 entries of C per table window the dense windows are the faster form.)
     if (sparse_max > 0 && major_rows > 0 && shared && nsub == 1) {
         const int w_end = w_first + chunk < nbase ? w_first + chunk : nbase;
         const int run_cnt = (w_end < nbase ? pre[w_end] : row_cnt) - pre[w_first];
@@ -2482,7 +2483,7 @@ constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + 
 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC, bool TWO = false>
 constexpr size_t win_lds_bytes() {
-    return (NUMERIC ? (size_t)WORDS * (THREADS <= 512 || TWO ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
+    return (NUMERIC ? (size_t)WORDS * (THREADS <= 256 || TWO ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
            (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
            (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0) +  // adaptive-window sums (at most 1024 table windows), wave bases
            (TWO ? 16 + (size_t)THREADS * 8 * 6 : 0);                               // two-level windows: fine words and their rank prefix
@@ -2854,17 +2855,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             heavy.n_w = bins.n_w - nl;
             light.list_w = bins.list_w + heavy.n_w;
             light.n_w = nl;
-            if (heavy.n_w > 0) {
-                // 512-thread workgroups, two per CU (adaptive windows of a table with 16384-column windows only)
-                if (ctx->win_two && ctx->win_threads == 512 && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
-                    CHK((launch_win<512, 1024, 4096, 8, 4, NUMERIC, true>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
-                else if (ctx->win_two && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
-                    CHK((launch_win<1024, 2048, 8192, 8, 4, NUMERIC, true>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
-                else if (ctx->win_threads == 512 && ctx->adaptive && bins.nbase <= 1024 && bins.shift <= 14)
-                    CHK((launch_win<512, 4096, 4096, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
-                else
-                    CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
-            }
+            if (heavy.n_w > 0) CHK((launch_win<1024, 8192, 8192, 8, 4, NUMERIC>(ctx, A, B, heavy, rowcnt, c_ip, row_beg, c_ix, c_val)));
             if (light.n_w > 0) {
                 phase_end(ctx, ph);
                 ph = phase_begin(ctx, SPMM_PH_LIGHT_NUM);

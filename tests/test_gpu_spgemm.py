@@ -36,7 +36,6 @@ PLANS = {
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
                            "SPMM_SLAB_THREADS": "256"},
-    "cursor_two_level": {"SPMM_WIN_TWO": "1", "SPMM_LIGHT_MAX": "0"},
     "sorted_rows_up_to_8192": {"SPMM_ESC_MAX": "8192"},
     "sorted_rows_up_to_512": {"SPMM_ESC_MAX": "512"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
