@@ -401,7 +401,10 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
 // The tiny rows of the smallest bin, 64/L per 64-lane workgroup.  Such a row is a chain of five dependent gathers
 // of a few dozen bytes each (list, row pointers of A, entries of A, row pointers of B, entries of B): latency, not
 // bandwidth, is its cost, so a row of at most QC products is expanded, sorted and compressed by L lanes in its
-// share of the LDS arrays and the wave keeps the chains of 64/L rows in flight.
+// share of the LDS arrays and the wave keeps the chains of 64/L rows in flight.  (Measured and not kept: merging the
+// entries' ascending runs by rank, a binary search per product and other run, instead of the sorting network: the
+// searches are chains of dependent LDS reads, the network's stages are not; 0.43 + 0.82 -> 0.55 + 0.89 ms on a
+// web-Google-sized graph.)
 template <int L, int QC, bool NUMERIC>
 __global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ list, const int n_list, const int32_t* __restrict__ a_ip,
                                              const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
@@ -2228,7 +2231,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 }
 
 // ---------------------------------------------------------------------------
-// Symbolic phase of the light window rows: 256-thread workgroups of 33 KB, four per CU, with the two-level windows of
+// Symbolic phase of the light window rows: 256-thread workgroups of 26 KB, six per CU, with the two-level windows of
 // the numeric light kernel.  A row of few products in a wide matrix costs k_symd a fixed price per 2^20 columns
 // (a pass over all entries and a count over the 128 KB bitmap); here a window is cut by its S2_CAP products: the
 // products go to registers and set one bit per group of 32 columns, every touched group gets a word of `fine` in
@@ -2236,8 +2239,8 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 // is the number of bits in the fine words.  A window that the products of one table window overfill, and every
 // window of a row with more than 256 entries, uses `fine` as a plain bitmap over at most 2^16 columns and reads
 // its products through the directory cursor instead.
-constexpr int S2_THREADS = 256, S2_WORDS = 2048, S2_U = 8, S2_CAP = S2_U * S2_THREADS;
-__global__ void __launch_bounds__(S2_THREADS, 4) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+constexpr int S2_THREADS = 256, S2_WORDS = 1024, S2_U = 8, S2_CAP = S2_U * S2_THREADS;
+__global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                         const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
                                                         const int32_t* __restrict__ winptr, int nbase, int shift,
                                                         int32_t* __restrict__ rowcnt) {

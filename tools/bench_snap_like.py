@@ -2,7 +2,7 @@
 """C = A*A on graphs of the size and rough shape of the SNAP inputs the benchmark names (web-Google, sx-askubuntu; the
 files are not available offline, spmm_amd.synth draws stand-ins): device-resident symbolic + numeric through the C ABI,
 timed per step, the whole of C compared with the oracle bit for bit, and the oracle timed on one host core beside it.
-One JSON line per graph.  usage: bench_snap_like.py [steps]"""
+One JSON line per graph.  usage: bench_snap_like.py [steps [graph]]"""
 import json
 import os
 import sys
@@ -21,8 +21,11 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    only = sys.argv[2] if len(sys.argv) > 2 else None      # a graph name: that graph alone (for a kernel trace)
     for name, n, gen in (("web-Stanford-like", 281903, synth.stanford_like), ("web-Google-like", 916428, synth.web_like),
                          ("sx-askubuntu-like", 159316, synth.askubuntu_like)):
+        if only and name != only:
+            continue
         row, col = gen()
         ip, ix, d = orc.csr_from_coo(n, row, col)
         nnz = int(ix.size)
