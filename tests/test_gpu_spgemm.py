@@ -32,6 +32,7 @@ PLANS = {
     "dense_window_major": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4"},
     "dense_window_major_no_sparse_runs": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_SPARSE": "0"},
     "dense_window_major_mixed_runs": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_SPARSE": "200"},
+    "dense_window_major_runs_of_16": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "16"},
     "sliced_launches": {"SPMM_MAX_GRID_THREADS": "8192", "SPMM_DENSE_MIN": "1"},
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
@@ -398,6 +399,55 @@ def test_product_sorted_rows_with_many_empty_b_rows(ctx):
     ci, cd = ctx.spgemm_numeric(A, B, c_ip)
     oi, od, _ = orc.spgemm_numeric(ncol, (a_ip, a_ix, a_d), (b_ip, b_ix, b_d), o_ip)
     assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+
+
+def test_light_rows_with_many_entries():
+    """Light window rows (the 256-thread workgroups of both phases) whose row of A has more than 256 entries: the
+    directory is then built chunk by chunk and the windows stay plain bitmaps; rows of fewer entries beside them take
+    the two-level windows; one row's first table window overfills a register-resident window.  Both light forms."""
+    import os
+    rng = np.random.default_rng(77)
+    nb_rows, ncol = 3000, 600000               # B: 3000 x 600000 (37 table windows)
+    b_cols = []
+    for k in range(nb_rows):
+        if k < 2900:                           # short rows spread over all columns
+            c = np.unique(rng.integers(0, ncol, rng.integers(5, 40)))
+        else:                                  # rows crowded into the first table window
+            c = np.unique(rng.integers(0, 16000, 60))
+        b_cols.append(c)
+    b_ip = np.zeros(nb_rows + 1, np.int32)
+    b_ip[1:] = np.cumsum([c.size for c in b_cols])
+    b_ix = np.concatenate(b_cols).astype(np.int32)
+    b_d = rng.integers(1, 5, b_ix.size).astype(np.float64)
+    a_rows = [np.unique(rng.integers(0, 2900, m)) for m in (700, 300, 257, 40, 1000)]
+    a_rows.append(np.arange(2900, 3000))       # 100 entries x 60: about 6000 products in table window 0
+    a_rows.append(np.zeros(0, np.int64))
+    na = len(a_rows)
+    a_ip = np.zeros(na + 1, np.int32)
+    a_ip[1:] = np.cumsum([c.size for c in a_rows])
+    a_ix = np.concatenate(a_rows).astype(np.int32)
+    a_d = rng.integers(1, 5, a_ix.size).astype(np.float64)
+    assert (np.diff(a_ip) > 256).sum() >= 3
+    A = capi.Csr(na, nb_rows, a_ip, a_ix, a_d)
+    B = capi.Csr(nb_rows, ncol, b_ip, b_ix, b_d)
+    o_ip = orc.spgemm_symbolic(na, ncol, a_ip, a_ix, b_ip, b_ix)
+    oi, od, _ = orc.spgemm_numeric(ncol, (a_ip, a_ix, a_d), (b_ip, b_ix, b_d), o_ip)
+    for env in ({"SPMM_LIGHT_MAX": "65535"}, {"SPMM_LIGHT_MAX": "65535", "SPMM_LIGHT_TWO": "0", "SPMM_LIGHT_SYM": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            c = capi.Context(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        c_ip, nnz_c, prods = c.spgemm_symbolic(A, B)
+        assert np.array_equal(c_ip, o_ip)
+        ci, cd = c.spgemm_numeric(A, B, c_ip)
+        assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+        c.close()
 
 
 def test_plan_threshold_follows_window_count():
