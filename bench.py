@@ -236,6 +236,9 @@ def main():
         stamps["numeric"]["cycles_per_window"] = round(float(st[16:24].sum() / max(st[24], 1)))
         # 1024-thread form only: its register-resident windows (the three skew slots above are then not skews)
         stamps["numeric"]["fast1024"] = dict(windows=int(st[28]), cycles=int(st[29]), products=int(st[30]))
+        if os.environ.get("SPMM_WIN_STAMPS") == "2":     # register-resident windows of the 1024-thread form by products held
+            stamps["numeric"]["fast1024_by_products"] = {nm: dict(windows=int(st[2 * i]), cycles=int(st[2 * i + 1]))
+                                                         for i, nm in enumerate(("below_2048", "below_4096", "below_6144", "from_6144"))}
         stamps["symbolic"]["cycles_per_window"] = round(float(st[0:8].sum() / max(st[8], 1)))
         # the dense kernel uses slots 0..5: sweep, wait for the sweep barrier, flags and sums, wait for the
         # scan barrier, stores, windows

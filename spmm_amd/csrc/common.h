@@ -96,6 +96,7 @@ struct spmm_ctx {
     long long slab_smax = 4194304;  // entries of B per window (its slab: 10 bytes an entry); fewer, heavier windows measured faster than L2-sized ones
     int dense_sparse = 8192;  // runs of table windows of a dense row with at most this many entries of C are one bitmap window (0 = off)
     int light_two = 1;        // light window rows: two-level windows (a bitmap bit per 32 columns, then a word per touched group)
+    int win_dense_over = 1;   // 1024-thread cursor kernel: a table window with more products than a register-resident window takes dense accumulators
     int light_sym = 1;        // symbolic phase of the light window rows on the small two-level workgroups (k_sym2) instead of k_symd
     int win_stamps = 0;   // diagnostic build of the window kernel with in-kernel cycle stamps
     int adaptive = 1;       // numeric k_win: window widths follow the row's product distribution

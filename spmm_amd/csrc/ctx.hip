@@ -60,6 +60,7 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     if (const char* e = getenv("SPMM_ADAPTIVE")) c->adaptive = atoi(e);
     if (const char* e = getenv("SPMM_DENSE_SPARSE")) c->dense_sparse = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("SPMM_LIGHT_TWO")) c->light_two = atoi(e);
+    if (const char* e = getenv("SPMM_WIN_DENSE_OVER")) c->win_dense_over = atoi(e);
     if (const char* e = getenv("SPMM_LIGHT_SYM")) c->light_sym = atoi(e);
 #ifdef SPMM_DIAG
     if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);   // diagnostic builds only: results are wrong when nonzero

@@ -864,6 +864,211 @@ __global__ void __launch_bounds__(256) k_winptr(int32_t nrowB, const int32_t* __
 }
 
 // ---------------------------------------------------------------------------
+// Numeric phase for the product-heaviest rows: dense accumulators.  A window is DENSE_COLS
+// columns of C held as fp64 sums in LDS plus one flag byte per column; every product is read
+// once and added with ds_add_f64, and the output pass walks the flags in column order, so the
+// row comes out sorted.  The sweep has no workgroup barrier: each wave owns chunks of E entries
+// of the A row (E = 16/32/64 by row length, so that short rows still occupy all waves) and maps
+// products to lanes in three tiers: the first 64/E products of every entry by the lanes of that
+// entry, entries with up to 128 further products by 16-lane groups, longer ones by the whole
+// wave.  Rows with at most 16*E entries keep (table row, value, window bound) in registers.
+// When the table windows are wider than DENSE_COLS the window is swept once per sub-range and
+// products outside the sub-range are skipped.
+constexpr int DENSE_COLS = 16384;
+// sparse runs of the dense kernel: sums and bitmap words that fit the accumulators' LDS (64 + 32 + 32 KiB)
+constexpr int DENSE_SPARSE_VALS = 8192, DENSE_SPARSE_WORDS = 8192;
+static_assert((size_t)DENSE_SPARSE_VALS * 8 + (size_t)DENSE_SPARSE_WORDS * 8 <= (size_t)DENSE_COLS * 8, "sparse-run arrays alias the accumulators");
+
+// `valid` selects lanes that hold a product.  The loaded column is consumed on every path (the
+// select below), so the wait for the load is unconditional too: a load whose only use sits in a
+// branch stays "pending" for the compiler on the other path, and the next reuse of its register
+// then drains every outstanding load and store (s_waitcnt vmcnt(0)), prefetches included.
+// Column lc of the window keeps its sum in slot lc ^ ((lc >> 4) & 15): the output pass gives thread t the columns
+// [16t, 16t+16), and without the rotation the lanes of a wave would read their j-th column from the same pair of LDS
+// banks (a stride of 128 bytes); with it the 64 lanes spread over all banks.
+__device__ __forceinline__ unsigned dense_slot(unsigned lc) { return lc ^ ((lc >> 4) & 15u); }
+__device__ __forceinline__ void dense_add(double* acc, uint8_t* flags, int col, int cbase, double v, bool valid = true) {
+    const unsigned lc = valid ? (unsigned)(col - cbase) : 0xffffffffu;
+    if (lc < (unsigned)DENSE_COLS) {
+        atomicAdd(&acc[dense_slot(lc)], v);
+        flags[lc] = 1;
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// Flattened wave-level sweep over what tier 1 left of the wave's entries: lanes hold (s, rem) =
+// start and count of the remaining products of their entry (rem <= 0: none).  The products of
+// all entries form one index space; a batch is 256 of them, four per lane, all loaded before
+// any is used.  wmap (256 bytes, private to the wave) maps a product of the batch to the lane
+// that holds its entry: entries mark the place where they start, a running maximum fills the
+// gaps.  act(col, a*b, valid) is called for every lane slot, valid for the products; b_val is
+// only read when WITH_VAL.  between() is called exactly once, after the loads of the first batch
+// have been issued (or at the end when there is no batch): work of the caller that consumes
+// earlier loads goes there, so that those and the batch's loads are in flight together.
+template <bool WITH_VAL, typename F, typename G>
+__device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12, int s,
+                                                int rem, double a, int lane, uint8_t* wmap, F&& act, G&& between) {
+    uint32_t* wmap4 = (uint32_t*)wmap;
+    rem = rem > 0 ? rem : 0;
+    int inc = rem;
+    if (WITH_VAL) {
+        inc = wave_inclusive_scan_i32(rem);
+    } else {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            inc += lane >= d ? o : 0;
+        }
+    }
+    const int R = __builtin_amdgcn_readlane(inc, 63);
+    const int o = inc - rem;     // index of the entry's first product
+    const int so = s - o;        // product q of this entry sits at so + q
+    for (int b0 = 0; b0 < R; b0 += 256) {
+        wmap4[lane] = 0u;
+        if (rem > 0 && o >= b0 && o < b0 + 256) wmap[o - b0] = (uint8_t)(lane + 1);
+        // the entry that holds product b0 when it started in an earlier batch (at most one lane)
+        const unsigned long long hold = __ballot(rem > 0 && o < b0 && o + rem > b0);
+        const int base = hold ? __ffsll(hold) : 0;
+        wave_sync_lds();   // the marks of the other lanes
+        const uint32_t raw = wmap4[lane];
+        int v0 = (int)(raw & 0xffu), v1 = (int)((raw >> 8) & 0xffu), v2 = (int)((raw >> 16) & 0xffu), v3 = (int)(raw >> 24);
+        v1 = v1 > v0 ? v1 : v0;
+        v2 = v2 > v1 ? v2 : v1;
+        v3 = v3 > v2 ? v3 : v2;
+        // (measured: the symbolic kernel, whose LDS pipeline is nearly idle, is faster with shuffles here)
+        int run = v3, before;
+        if (WITH_VAL) {
+            run = wave_inclusive_max_nonneg(v3);
+            before = dpp_shr1(run);
+        } else {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int x = __shfl_up(run, d, 64);
+                run = (lane >= d && x > run) ? x : run;
+            }
+            before = __shfl_up(run, 1, 64);
+        }
+        before = (lane != 0 && before > base) ? before : base;
+        v0 = v0 > before ? v0 : before;
+        v1 = v1 > before ? v1 : before;
+        v2 = v2 > before ? v2 : before;
+        v3 = v3 > before ? v3 : before;
+        wmap4[lane] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+        wave_sync_lds();   // the filled map of the other lanes
+        int cq[4], sq[4];
+        double bq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = b0 + j * 64 + lane;
+            const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last product
+            sq[j] = (int)wmap[qc - b0] - 1;
+            const int pos = __shfl(so, sq[j], 64) + qc;
+            if (WITH_VAL) {
+                const colval cv = ld_b12(b12, pos);
+                bq[j] = cv.val;
+                cq[j] = cv.col;
+            } else {
+                bq[j] = 0.0;
+                cq[j] = b_ix[pos];
+            }
+        }
+        if (b0 == 0) between();
+        // the entry's value of A is fetched while the loads are in flight (holding the source lane costs
+        // one register per product, the value two)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double aj = WITH_VAL ? __shfl(a, sq[j], 64) : 0.0;
+            act(cq[j], aj * bq[j], b0 + j * 64 + lane < R);
+        }
+    }
+    if (R <= 0) between();
+}
+
+// 16-byte stores to addresses that are only element aligned (the compiler splits such a store; the hardware
+// takes it).  The no-op keeps the next instruction from overwriting the data registers too early.
+typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_b128(int32_t* p, int a, int b, int c, int d) {
+    const v4i32 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_b128(double* p, double a, double b) {
+    const v2f64 v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+
+// ---------------------------------------------------------------------------
+// One table window of a cursor row that holds more products than a register-resident window, with dense accumulators
+// instead of the two cursor sweeps.  The cursor kernel's bitmap, rank prefixes and compact sums are one run of LDS
+// (acc_bytes from the start of the dynamic LDS, at least a sum per column of a table window), all zero here except
+// the rank prefixes, which are cleared first; every product is read once and added to its column's sum, a flag bit
+// per column marks the touched ones (in the directory buffer that is not in use, flags_off), and the output pass
+// walks the columns in order, 16 per thread, as the dense kernel's does.  Wave wv takes the entries lane*16 + wv of
+// the directory (dir_off: {offset, start} per entry, dirav_off: A's values), which spreads the long rows of B that
+// cluster at low column ids over the waves.  Returns the number of entries of C written at c_ix / c_val.  Not
+// inlined: the cursor kernel runs at the register limit of 1024-thread workgroups, and this code's registers would
+// push its common path into spills (measured: 395 -> 458 ms).
+template <int THREADS>
+__device__ __noinline__ __attribute__((cold)) int win_dense_window(uint32_t acc_bytes, uint32_t dir_off, uint32_t flags_off, uint32_t dirav_off,
+                                             uint32_t tmp_off, uint32_t pre_off, uint32_t pre_bytes,
+                                             const uint32_t* __restrict__ b12, int wbase, int32_t* __restrict__ c_ix,
+                                             double* __restrict__ c_val) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW = THREADS / 64;
+    static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* acc = (double*)smem;
+    const int2* dir = (const int2*)(smem + dir_off);
+    const double* dir_av = (const double*)(smem + dirav_off);
+    uint32_t* dflags = (uint32_t*)(smem + flags_off);                  // DENSE_COLS / 32 words
+    uint8_t* wmap = (uint8_t*)(dflags + DENSE_COLS / 32) + wv * 256;   // 256 bytes per wave
+    int32_t* tmp = (int32_t*)(smem + tmp_off);
+    (void)acc_bytes;
+    if (tid < DENSE_COLS / 32) dflags[tid] = 0u;
+    for (int i = tid; i < (int)(pre_bytes / 16); i += THREADS) ((uint4*)(smem + pre_off))[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int e = lane * NW + wv;
+    const int2 de = dir[e];
+    const int len_e = dir[e + 1].x - de.x;
+    const double a_e = dir_av[e];
+    __syncthreads();   // flags and rank prefixes cleared
+    wave_flat_sweep<true>(nullptr, b12, de.y, len_e, a_e, lane, wmap,
+                          [&](int col, double v, bool valid) {
+                              const unsigned lc = valid ? (unsigned)(col - wbase) : 0xffffffffu;
+                              if (lc < (unsigned)DENSE_COLS) {
+                                  atomicAdd(&acc[dense_slot(lc)], v);
+                                  atomicOr(&dflags[lc >> 5], 1u << (lc & 31));
+                              }
+                          },
+                          [] {});
+    __syncthreads();
+    // output: thread t owns columns [16t, 16t + 16) of the window, its 16 flag bits are half a word
+    const unsigned m16 = ((const uint16_t*)dflags)[tid];
+    int total;
+    const int r = block_exclusive_scan_1b<THREADS, int32_t>(__popc(m16), tmp, &total);
+    unsigned mm = m16;
+    int32_t* const pi = c_ix + r;
+    double* const pv = c_val + r;
+#pragma unroll 4
+    for (int i = 0; i < 16; i++) {
+        if (__ballot(mm != 0u) == 0ull) break;   // wave-uniform: sparse stretches leave early
+        if (mm) {
+            const int b = __ffs(mm) - 1;
+            mm &= mm - 1u;
+            const unsigned lc = dense_slot((unsigned)(tid * 16 + b));
+            pi[i] = wbase + tid * 16 + b;
+            pv[i] = acc[lc];
+            acc[lc] = 0.0;
+        }
+    }
+    __syncthreads();   // the next window clears its entry map, which lies inside these sums, right away
+    return total;
+}
+
+// ---------------------------------------------------------------------------
 // Window rows: one workgroup per row of A.
 //
 // LDS: bitmap of the current column window (WORDS x 32 columns), for numeric also the rank
@@ -941,7 +1146,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                                                  const int64_t* __restrict__ prod, int32_t* __restrict__ rowcnt,
                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val,
-                                                 unsigned long long* __restrict__ stamps, int dbg_arg, int adaptive) {
+                                                 unsigned long long* __restrict__ stamps, int dbg_arg, int adaptive, int dense_over) {
     static_assert(WORDS % THREADS == 0, "bitmap words must divide evenly");
 #ifdef SPMM_DIAG
     const int dbg = dbg_arg;       // timing experiments of the diagnostic build (results are wrong when nonzero)
@@ -994,7 +1199,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     int mycount = 0;
     // stamp accumulators live in LDS so that the diagnostic build keeps the register allocation
     unsigned long long* st_lds = (unsigned long long*)(((uintptr_t)(tmp + 3 * (NW + 1)) + 7) & ~(uintptr_t)7);
-    unsigned long long* st_arr = st_lds + 16;   // 5 x NW arrival times
+    unsigned long long* st_arr = st_lds + 24;   // 5 x NW arrival times; st_lds[16..23]: register-resident windows by products (count, cycles)
     // Adaptive windows (numeric): R-MAT-like rows put a quarter of their products into the first
     // few table windows, so equal-width windows sized by the row average overflow the registers
     // at the front and idle at the back.  cs[j] = sum over the row's entries of the table value at
@@ -1071,7 +1276,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     }
     unsigned long long win_t0 = 0;
     if (STAMP && tid == 0) {
-        for (int i = 0; i < 15; i++) st_lds[i] = 0;
+        for (int i = 0; i < 24; i++) st_lds[i] = 0;
         st_lds[15] = win_clock();
         win_t0 = st_lds[15];
     }
@@ -1113,6 +1318,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
             ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
             if (tid < NW) wave_ent[tid] = 0;
         }
+        bool dense_done = false;   // the window was finished with dense accumulators (block-uniform)
         for (int c0 = 0; c0 < lenA; c0 += THREADS) {
             if (!single_chunk) __syncthreads();   // earlier readers of the directory are done
             int s = 0, len = 0;
@@ -1156,6 +1362,25 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
             Tw += Tc;
             WIN_STAMP(0)   // directory
             if (Tc == 0) continue;
+            if constexpr (NUMERIC && !TWO && THREADS == 1024 && (size_t)WORDS * (4 + sizeof(pre_t)) + (size_t)VALS * 8 >= (size_t)DENSE_COLS * 8) {
+                // ---- a single table window that holds more products than a register-resident window ----------------
+                // Dense accumulators instead of the two cursor sweeps: the bitmap, the rank prefixes and the compact sums
+                // are one run of LDS, all zero here, large enough for a sum per column of the table window; every
+                // product is read once and added to its column's sum, a flag bit per column marks the touched ones (in
+                // the directory buffer that is not in use), and the output pass walks the columns in order, 16 per
+                // thread, as the dense kernel's does.  Wave wv takes the entries lane*16 + wv, which spreads the long
+                // rows of B that cluster at low column ids over the waves.
+                if (dense_over && single_chunk && !fast && w1 - w0 == 1 && shift <= 14) {
+                    // out of line, so that its registers do not weigh on the register-resident windows' allocation
+                    out += win_dense_window<THREADS>((uint32_t)WORDS * (uint32_t)(4 + sizeof(pre_t)) + (uint32_t)VALS * 8u,
+                                                     (uint32_t)((unsigned char*)dir - smem), (uint32_t)((unsigned char*)(dir_buf + (flip ^ 1) * (THREADS + 1)) - smem),
+                                                     (uint32_t)((unsigned char*)dir_av - smem), (uint32_t)((unsigned char*)tmp_pre - smem),
+                                                     (uint32_t)((unsigned char*)pre - smem), (uint32_t)(WORDS * sizeof(pre_t)),
+                                                     b12, wbase, c_ix + out, c_val + out);
+                    dense_done = true;
+                    continue;   // leaves the chunk loop (a single-chunk row has one chunk)
+                }
+            }
             const int p_lo = wv * per;
             const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
             if (p_lo >= p_hi) continue;   // this wave has no products in the chunk (wave-uniform)
@@ -1235,6 +1460,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
             }
         }
         WIN_STAMP(1)   // search + loads + bit atomics (this thread)
+        if (dense_done) continue;   // the next directory build starts with a barrier
         if (Tw == 0) continue;
         WIN_ARRIVE(0)
         __syncthreads();
@@ -1520,156 +1746,25 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         WIN_STAMP(6)   // output
         if (STAMP && THREADS == 1024 && tid == 0) {
             // register-resident windows of the 1024-thread form: count, cycles (since the previous counted window), products
-            if (fast) { st_lds[12] += 1; st_lds[13] += st_lds[15] - win_t0; st_lds[14] += (unsigned long long)Tw; }
+            if (fast) {
+                st_lds[12] += 1; st_lds[13] += st_lds[15] - win_t0; st_lds[14] += (unsigned long long)Tw;
+                const int cls = Tw < 2048 ? 0 : Tw < 4096 ? 1 : Tw < 6144 ? 2 : 3;
+                st_lds[16 + 2 * cls] += 1;
+                st_lds[17 + 2 * cls] += st_lds[15] - win_t0;
+            }
             win_t0 = st_lds[15];
         }
         // the next directory build starts with a barrier
     }
     if (STAMP && tid == 0)
         for (int i = 0; i < 15; i++) atomicAdd(&stamps[i], st_lds[i]);
+    if (STAMP && THREADS == 1024 && NUMERIC && tid == 0)   // the class sums go to the symbolic half of the stamp array (slots 0..7 of it), unused by k_symd
+        for (int i = 0; i < 8; i++) atomicAdd(&stamps[i - 16], st_lds[16 + i]);
     if (!NUMERIC) {
         int tot;
         block_exclusive_scan<THREADS, int32_t>(mycount, tmp, &tot);
         if (tid == 0) rowcnt[row] = tot;
     }
-}
-
-// ---------------------------------------------------------------------------
-// Numeric phase for the product-heaviest rows: dense accumulators.  A window is DENSE_COLS
-// columns of C held as fp64 sums in LDS plus one flag byte per column; every product is read
-// once and added with ds_add_f64, and the output pass walks the flags in column order, so the
-// row comes out sorted.  The sweep has no workgroup barrier: each wave owns chunks of E entries
-// of the A row (E = 16/32/64 by row length, so that short rows still occupy all waves) and maps
-// products to lanes in three tiers: the first 64/E products of every entry by the lanes of that
-// entry, entries with up to 128 further products by 16-lane groups, longer ones by the whole
-// wave.  Rows with at most 16*E entries keep (table row, value, window bound) in registers.
-// When the table windows are wider than DENSE_COLS the window is swept once per sub-range and
-// products outside the sub-range are skipped.
-constexpr int DENSE_COLS = 16384;
-// sparse runs of the dense kernel: sums and bitmap words that fit the accumulators' LDS (64 + 32 + 32 KiB)
-constexpr int DENSE_SPARSE_VALS = 8192, DENSE_SPARSE_WORDS = 8192;
-static_assert((size_t)DENSE_SPARSE_VALS * 8 + (size_t)DENSE_SPARSE_WORDS * 8 <= (size_t)DENSE_COLS * 8, "sparse-run arrays alias the accumulators");
-
-// `valid` selects lanes that hold a product.  The loaded column is consumed on every path (the
-// select below), so the wait for the load is unconditional too: a load whose only use sits in a
-// branch stays "pending" for the compiler on the other path, and the next reuse of its register
-// then drains every outstanding load and store (s_waitcnt vmcnt(0)), prefetches included.
-// Column lc of the window keeps its sum in slot lc ^ ((lc >> 4) & 15): the output pass gives thread t the columns
-// [16t, 16t+16), and without the rotation the lanes of a wave would read their j-th column from the same pair of LDS
-// banks (a stride of 128 bytes); with it the 64 lanes spread over all banks.
-__device__ __forceinline__ unsigned dense_slot(unsigned lc) { return lc ^ ((lc >> 4) & 15u); }
-__device__ __forceinline__ void dense_add(double* acc, uint8_t* flags, int col, int cbase, double v, bool valid = true) {
-    const unsigned lc = valid ? (unsigned)(col - cbase) : 0xffffffffu;
-    if (lc < (unsigned)DENSE_COLS) {
-        atomicAdd(&acc[dense_slot(lc)], v);
-        flags[lc] = 1;
-    }
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
-                            __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-
-// Flattened wave-level sweep over what tier 1 left of the wave's entries: lanes hold (s, rem) =
-// start and count of the remaining products of their entry (rem <= 0: none).  The products of
-// all entries form one index space; a batch is 256 of them, four per lane, all loaded before
-// any is used.  wmap (256 bytes, private to the wave) maps a product of the batch to the lane
-// that holds its entry: entries mark the place where they start, a running maximum fills the
-// gaps.  act(col, a*b, valid) is called for every lane slot, valid for the products; b_val is
-// only read when WITH_VAL.  between() is called exactly once, after the loads of the first batch
-// have been issued (or at the end when there is no batch): work of the caller that consumes
-// earlier loads goes there, so that those and the batch's loads are in flight together.
-template <bool WITH_VAL, typename F, typename G>
-__device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12, int s,
-                                                int rem, double a, int lane, uint8_t* wmap, F&& act, G&& between) {
-    uint32_t* wmap4 = (uint32_t*)wmap;
-    rem = rem > 0 ? rem : 0;
-    int inc = rem;
-    if (WITH_VAL) {
-        inc = wave_inclusive_scan_i32(rem);
-    } else {
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(inc, d, 64);
-            inc += lane >= d ? o : 0;
-        }
-    }
-    const int R = __builtin_amdgcn_readlane(inc, 63);
-    const int o = inc - rem;     // index of the entry's first product
-    const int so = s - o;        // product q of this entry sits at so + q
-    for (int b0 = 0; b0 < R; b0 += 256) {
-        wmap4[lane] = 0u;
-        if (rem > 0 && o >= b0 && o < b0 + 256) wmap[o - b0] = (uint8_t)(lane + 1);
-        // the entry that holds product b0 when it started in an earlier batch (at most one lane)
-        const unsigned long long hold = __ballot(rem > 0 && o < b0 && o + rem > b0);
-        const int base = hold ? __ffsll(hold) : 0;
-        wave_sync_lds();   // the marks of the other lanes
-        const uint32_t raw = wmap4[lane];
-        int v0 = (int)(raw & 0xffu), v1 = (int)((raw >> 8) & 0xffu), v2 = (int)((raw >> 16) & 0xffu), v3 = (int)(raw >> 24);
-        v1 = v1 > v0 ? v1 : v0;
-        v2 = v2 > v1 ? v2 : v1;
-        v3 = v3 > v2 ? v3 : v2;
-        // (measured: the symbolic kernel, whose LDS pipeline is nearly idle, is faster with shuffles here)
-        int run = v3, before;
-        if (WITH_VAL) {
-            run = wave_inclusive_max_nonneg(v3);
-            before = dpp_shr1(run);
-        } else {
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int x = __shfl_up(run, d, 64);
-                run = (lane >= d && x > run) ? x : run;
-            }
-            before = __shfl_up(run, 1, 64);
-        }
-        before = (lane != 0 && before > base) ? before : base;
-        v0 = v0 > before ? v0 : before;
-        v1 = v1 > before ? v1 : before;
-        v2 = v2 > before ? v2 : before;
-        v3 = v3 > before ? v3 : before;
-        wmap4[lane] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-        wave_sync_lds();   // the filled map of the other lanes
-        int cq[4], sq[4];
-        double bq[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int q = b0 + j * 64 + lane;
-            const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last product
-            sq[j] = (int)wmap[qc - b0] - 1;
-            const int pos = __shfl(so, sq[j], 64) + qc;
-            if (WITH_VAL) {
-                const colval cv = ld_b12(b12, pos);
-                bq[j] = cv.val;
-                cq[j] = cv.col;
-            } else {
-                bq[j] = 0.0;
-                cq[j] = b_ix[pos];
-            }
-        }
-        if (b0 == 0) between();
-        // the entry's value of A is fetched while the loads are in flight (holding the source lane costs
-        // one register per product, the value two)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const double aj = WITH_VAL ? __shfl(a, sq[j], 64) : 0.0;
-            act(cq[j], aj * bq[j], b0 + j * 64 + lane < R);
-        }
-    }
-    if (R <= 0) between();
-}
-
-// 16-byte stores to addresses that are only element aligned (the compiler splits such a store; the hardware
-// takes it).  The no-op keeps the next instruction from overwriting the data registers too early.
-typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
-typedef double v2f64 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store_b128(int32_t* p, int a, int b, int c, int d) {
-    const v4i32 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store_b128(double* p, double a, double b) {
-    const v2f64 v = {a, b};
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 
 #ifndef DENSE_TQ
@@ -2487,7 +2582,7 @@ constexpr size_t dense_lds_bytes(int threads) { return (size_t)DENSE_COLS * 9 + 
 template <int THREADS, int WORDS, int VALS, bool NUMERIC, bool TWO = false>
 constexpr size_t win_lds_bytes() {
     return (NUMERIC ? (size_t)WORDS * (THREADS <= 256 || TWO ? 6 : 8) + (size_t)VALS * 8 + (size_t)THREADS * 8 : (size_t)WORDS * 4) +
-           (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 16 * 8 + 5 * (THREADS / 64) * 8 +
+           (size_t)(THREADS + 1) * 16 + (size_t)(THREADS / 64 + 1) * 12 + 16 + 24 * 8 + 5 * (THREADS / 64) * 8 +
            (NUMERIC ? (size_t)(1024 + 2) * 4 + (size_t)(THREADS / 64) * 4 : 0) +  // adaptive-window sums (at most 1024 table windows), wave bases
            (TWO ? 16 + (size_t)THREADS * 8 * 6 : 0);                               // two-level windows: fine words and their rank prefix
 }
@@ -2771,7 +2866,7 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
         hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(THREADS), lds, ctx->stream, bins.list_w + off, A->indptr,
                            A->indices, A->data, B->indices, bins.b12, bins.winptr, bins.nbase, bins.shift, bins.prod, rowcnt,
                            c_ip, row_beg, c_ix, c_val, stamps + (NUMERIC ? 16 : 0), NUMERIC ? ctx->win_dbg : 0,
-                           (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0);
+                           (NUMERIC && ctx->adaptive && bins.nbase <= 1024) ? 1 : 0, ctx->win_dense_over);
     });
     return SPMM_OK;
 }

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 # runs of 4 table windows, one workgroup each (runs with few entries of C as one bitmap window: by default up to 8192
 # entries, never, and up to 200 so that both forms meet in one row); every window
 # row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes), with two-level
-# windows (a bitmap bit per 32 columns) and with plain ones; the sorting kernels for rows of up to 8192 products (the
+# windows (a bitmap bit per 32 columns) and with plain ones; the 1024-thread cursor kernel with two cursor sweeps
+# instead of dense accumulators for a table window that overfills a register-resident window; the sorting kernels for rows of up to 8192 products (the
 # default is 4096) and of up to 512 only; no window table of
 # B at all (every window row through the launches over B's slab order), with wide windows and dense accumulators,
 # and with narrow windows, the bitmap-rank accumulators and 256-thread workgroups.
@@ -37,6 +38,7 @@ PLANS = {
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
                            "SPMM_SLAB_THREADS": "256"},
+    "cursor_overfull_windows_in_two_sweeps": {"SPMM_WIN_DENSE_OVER": "0"},
     "sorted_rows_up_to_8192": {"SPMM_ESC_MAX": "8192"},
     "sorted_rows_up_to_512": {"SPMM_ESC_MAX": "512"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
