@@ -1012,22 +1012,25 @@ __device__ __forceinline__ void store_b128(double* p, double a, double b) {
 // cluster at low column ids over the waves.  Returns the number of entries of C written at c_ix / c_val.  Not
 // inlined: the cursor kernel runs at the register limit of 1024-thread workgroups, and this code's registers would
 // push its common path into spills (measured: 395 -> 458 ms).
-template <int THREADS>
-__device__ __noinline__ __attribute__((cold)) int win_dense_window(uint32_t acc_bytes, uint32_t dir_off, uint32_t flags_off, uint32_t dirav_off,
-                                             uint32_t tmp_off, uint32_t pre_off, uint32_t pre_bytes,
-                                             const uint32_t* __restrict__ b12, int wbase, int32_t* __restrict__ c_ix,
-                                             double* __restrict__ c_val) {
+template <int THREADS, int WORDS, int VALS, int PRE_BYTES>
+__device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, const uint32_t* __restrict__ b12, int wbase,
+                                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    // the cursor kernel's numeric LDS layout: bitmap, rank prefixes, compact sums, A's values, two directory buffers,
+    // three scan buffers
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int NW = THREADS / 64;
+    constexpr uint32_t pre_off = (uint32_t)WORDS * 4u, pre_bytes = (uint32_t)WORDS * (uint32_t)PRE_BYTES;
+    constexpr uint32_t dirav_off = pre_off + pre_bytes + (uint32_t)VALS * 8u, dirbuf_off = dirav_off + (uint32_t)THREADS * 8u;
+    constexpr uint32_t tmp_off = dirbuf_off + 2u * (uint32_t)(THREADS + 1) * 8u + 2u * (uint32_t)(NW + 1) * 4u;   // the rank prefix's scan buffer
     static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
+    static_assert(dirav_off >= (uint32_t)DENSE_COLS * 8u, "a sum per column of a table window");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* acc = (double*)smem;
-    const int2* dir = (const int2*)(smem + dir_off);
+    const int2* dir = (const int2*)(smem + dirbuf_off) + flip * (THREADS + 1);
     const double* dir_av = (const double*)(smem + dirav_off);
-    uint32_t* dflags = (uint32_t*)(smem + flags_off);                  // DENSE_COLS / 32 words
+    uint32_t* dflags = (uint32_t*)((int2*)(smem + dirbuf_off) + (flip ^ 1) * (THREADS + 1));   // DENSE_COLS / 32 words
     uint8_t* wmap = (uint8_t*)(dflags + DENSE_COLS / 32) + wv * 256;   // 256 bytes per wave
     int32_t* tmp = (int32_t*)(smem + tmp_off);
-    (void)acc_bytes;
     if (tid < DENSE_COLS / 32) dflags[tid] = 0u;
     for (int i = tid; i < (int)(pre_bytes / 16); i += THREADS) ((uint4*)(smem + pre_off))[i] = make_uint4(0u, 0u, 0u, 0u);
     const int e = lane * NW + wv;
@@ -1372,11 +1375,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 // rows of B that cluster at low column ids over the waves.
                 if (dense_over && single_chunk && !fast && w1 - w0 == 1 && shift <= 14) {
                     // out of line, so that its registers do not weigh on the register-resident windows' allocation
-                    out += win_dense_window<THREADS>((uint32_t)WORDS * (uint32_t)(4 + sizeof(pre_t)) + (uint32_t)VALS * 8u,
-                                                     (uint32_t)((unsigned char*)dir - smem), (uint32_t)((unsigned char*)(dir_buf + (flip ^ 1) * (THREADS + 1)) - smem),
-                                                     (uint32_t)((unsigned char*)dir_av - smem), (uint32_t)((unsigned char*)tmp_pre - smem),
-                                                     (uint32_t)((unsigned char*)pre - smem), (uint32_t)(WORDS * sizeof(pre_t)),
-                                                     b12, wbase, c_ix + out, c_val + out);
+                    out += win_dense_window<THREADS, WORDS, VALS, (int)sizeof(pre_t)>(flip, b12, wbase, c_ix + out, c_val + out);
                     dense_done = true;
                     continue;   // leaves the chunk loop (a single-chunk row has one chunk)
                 }
