@@ -1050,21 +1050,53 @@ __device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, con
     __syncthreads();
     // output: thread t owns columns [16t, 16t + 16) of the window, its 16 flag bits are half a word
     const unsigned m16 = ((const uint16_t*)dflags)[tid];
+    // sums leave LDS (and the slots are cleared) before the scan barrier
+    double vr[16];
+    const bool wave_has = __ballot(m16 != 0u) != 0ull;
+    if (wave_has) {
+        unsigned mm = m16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (__ballot(mm != 0u) == 0ull) break;   // wave-uniform: sparse stretches leave after a few steps
+            if (mm) {
+                const unsigned lc = dense_slot((unsigned)(tid * 16 + __ffs(mm) - 1));
+                mm &= mm - 1u;
+                vr[i] = acc[lc];
+                acc[lc] = 0.0;
+            }
+        }
+    }
     int total;
     const int r = block_exclusive_scan_1b<THREADS, int32_t>(__popc(m16), tmp, &total);
-    unsigned mm = m16;
-    int32_t* const pi = c_ix + r;
-    double* const pv = c_val + r;
-#pragma unroll 4
-    for (int i = 0; i < 16; i++) {
-        if (__ballot(mm != 0u) == 0ull) break;   // wave-uniform: sparse stretches leave early
-        if (mm) {
-            const int b = __ffs(mm) - 1;
-            mm &= mm - 1u;
-            const unsigned lc = dense_slot((unsigned)(tid * 16 + b));
-            pi[i] = wbase + tid * 16 + b;
-            pv[i] = acc[lc];
-            acc[lc] = 0.0;
+    if (wave_has) {
+        // a thread's entries are consecutive in C: column ids four per store, values two per store, single stores
+        // for what is left
+        const int cnt = __popc(m16);
+        int32_t* const pi = c_ix + r;
+        double* const pv = c_val + r;
+        unsigned mm = m16;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (__ballot(cnt > 4 * g) == 0ull) break;   // wave-uniform
+            int id[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                id[j] = wbase + tid * 16 + __ffs(mm) - 1;   // garbage once mm is empty, not stored then
+                mm &= mm - 1u;
+            }
+            if (cnt >= 4 * g + 4) {
+                store_b128(pi + 4 * g, id[0], id[1], id[2], id[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (cnt > 4 * g + j) pi[4 * g + j] = id[j];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            if (__ballot(cnt > 2 * g) == 0ull) break;
+            if (cnt >= 2 * g + 2) store_b128(pv + 2 * g, vr[2 * g], vr[2 * g + 1]);
+            else if (cnt == 2 * g + 1) pv[2 * g] = vr[2 * g];
         }
     }
     __syncthreads();   // the next window clears its entry map, which lies inside these sums, right away
