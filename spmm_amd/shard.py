@@ -68,7 +68,7 @@ def product_balanced_bounds(prod, world):
 # per entry next to 2.6 ps per product when the row lengths are given, a quarter more for the rows of more than
 # 8192 entries that several workgroups share; 6.5 ps per product stands for both when they are not.  Only the
 # ratios matter.
-COST_NS = {"dense": 0.0065, "window": 0.00755, "light": 0.0091, "sorted": 0.0239}
+COST_NS = {"dense": 0.0065, "window": 0.0073, "light": 0.0091, "sorted": 0.0239}
 ROW_NS = {"dense": 0.0, "window": 125.0, "light": 62.0, "sorted": 6.6}
 DENSE_WITH_LENS_NS = 0.0026
 DENSE_ENTRY_NS = 7.2
