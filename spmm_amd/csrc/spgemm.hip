@@ -1004,12 +1004,12 @@ __device__ __forceinline__ void store_b128(double* p, double a, double b) {
 // ---------------------------------------------------------------------------
 // One table window of a cursor row that holds more products than a register-resident window, with dense accumulators
 // instead of the two cursor sweeps.  The cursor kernel's bitmap, rank prefixes and compact sums are one run of LDS
-// (acc_bytes from the start of the dynamic LDS, at least a sum per column of a table window), all zero here except
+// (from the start of the dynamic LDS, at least a sum per column of a table window), all zero here except
 // the rank prefixes, which are cleared first; every product is read once and added to its column's sum, a flag bit
-// per column marks the touched ones (in the directory buffer that is not in use, flags_off), and the output pass
-// walks the columns in order, 16 per thread, as the dense kernel's does.  Wave wv takes the entries lane*16 + wv of
-// the directory (dir_off: {offset, start} per entry, dirav_off: A's values), which spreads the long rows of B that
-// cluster at low column ids over the waves.  Returns the number of entries of C written at c_ix / c_val.  Not
+// per column marks the touched ones (in the directory buffer that is not in use: `flip` names the one that is), and
+// the output pass walks the columns in order, 16 per thread, as the dense kernel's does.  Wave wv takes the entries
+// lane*16 + wv of the directory ({offset, start} per entry; A's values beside it), which spreads the long rows of B
+// that cluster at low column ids over the waves.  Returns the number of entries of C written at c_ix / c_val.  Not
 // inlined: the cursor kernel runs at the register limit of 1024-thread workgroups, and this code's registers would
 // push its common path into spills (measured: 395 -> 458 ms).
 template <int THREADS, int WORDS, int VALS, int PRE_BYTES>
@@ -1024,6 +1024,7 @@ __device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, con
     constexpr uint32_t tmp_off = dirbuf_off + 2u * (uint32_t)(THREADS + 1) * 8u + 2u * (uint32_t)(NW + 1) * 4u;   // the rank prefix's scan buffer
     static_assert(DENSE_COLS == 16 * THREADS, "the output pass gives every thread 16 columns");
     static_assert(dirav_off >= (uint32_t)DENSE_COLS * 8u, "a sum per column of a table window");
+    static_assert((size_t)(THREADS + 1) * 8 >= DENSE_COLS / 8 + NW * 256, "flag bits and wave maps fit one directory buffer");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* acc = (double*)smem;
     const int2* dir = (const int2*)(smem + dirbuf_off) + flip * (THREADS + 1);
