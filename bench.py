@@ -226,7 +226,7 @@ def main():
            ("slab_plan", capi.PH_SLAB_PLAN)]}
     ctx.profile(False)
     stamps = None
-    if os.environ.get("SPMM_WIN_STAMPS") in ("1", "2"):
+    if os.environ.get("SPMM_WIN_STAMPS") in ("1", "2", "3"):
         st = ctx.debug_stamps().astype(np.float64)
         names = ["directory", "sweep_own", "sweep_wait", "prefix", "value_own", "value_wait", "output_rest", "output_vals", "windows", "products"]
         stamps = {k: {n: (round(float(v)) if n in ("windows", "products") else round(float(v) / max(st[o:o + 8].sum(), 1), 3))
@@ -239,6 +239,9 @@ def main():
         if os.environ.get("SPMM_WIN_STAMPS") == "2":     # register-resident windows of the 1024-thread form by products held
             stamps["numeric"]["fast1024_by_products"] = {nm: dict(windows=int(st[2 * i]), cycles=int(st[2 * i + 1]))
                                                          for i, nm in enumerate(("below_2048", "below_4096", "below_6144", "from_6144"))}
+        if os.environ.get("SPMM_WIN_STAMPS") == "3":     # 256-thread workgroups only: set-up and whole-row cycles of thread 0
+            stamps["numeric"]["small_workgroups"] = dict(rows=int(st[2]), setup_cycles_per_row=round(float(st[0] / max(st[2], 1))),
+                                                         cycles_per_row=round(float(st[1] / max(st[2], 1))))
         stamps["symbolic"]["cycles_per_window"] = round(float(st[0:8].sum() / max(st[8], 1)))
         # the dense kernel uses slots 0..5: sweep, wait for the sweep barrier, flags and sums, wait for the
         # scan barrier, stores, windows

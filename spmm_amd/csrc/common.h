@@ -43,7 +43,7 @@ void spmm_set_error(const char* fmt, ...);
 enum ws_slot {
     WS_SCAN_SUMS = 0, WS_RADIX_HIST, WS_RADIX_K0, WS_RADIX_V0, WS_RADIX_K1, WS_RADIX_V1,
     WS_PROD, WS_ROWCLASS, WS_LIST_ESC_S, WS_LIST_ESC_L, WS_LIST_ESC_M, WS_LIST_GIANT, WS_GSLOT, WS_WCNT, WS_LIST_WIN, WS_COUNTERS, WS_ROWCNT,
-    WS_WINPTR, WS_B12, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
+    WS_WINPTR, WS_B12, WS_DBOUND, WS_DOFF, WS_DAVAL, WS_STAMPS, WS_MISC0, WS_MISC1, WS_MISC2, WS_MISC3, WS_MISC4, WS_MISC5, WS_MISC6,
     WS_MISC7, WS_P0, WS_P1, WS_P2, WS_P3, WS_P4, WS_P5, WS_P6, WS_P7, WS_UP0, WS_UP1, WS_UP2, WS_UP3, WS_UP4, WS_UP5, WS_UP6, WS_UP7, WS_UP8, WS_UP9,
     // slab order of B for the window launches over the heaviest rows: kept between symbolic and numeric (PERM .. SLOTROW), scratch of the build (T0 .. T5)
     WS_SL_PERM, WS_SL_COL, WS_SL_VAL, WS_SL_PIECE, WS_SL_PFIRST, WS_SL_PFIRSTW, WS_SL_CUR, WS_SL_NW, WS_SL_CNT, WS_SL_WB, WS_SL_LUT, WS_SL_SLOTROW, WS_SL_EBASE, WS_SL_WROW, WS_SL_ITEMS, WS_SL_ITEMA, WS_SL_RCOUNT, WS_SL_TICKET, WS_SL_AROW0, WS_SL_OBASE, WS_SL_CNTR,
@@ -67,7 +67,7 @@ struct plan_cache {
     // the row lists of the last classification, reusable by a numeric call over the same rows of the same matrices
     bool lists_valid = false;
     int l_row_beg = 0, l_row_end = 0;
-    long long l_n_s = 0, l_n_t = 0, l_n_l = 0, l_n_m = 0, l_n_w = 0, l_n_g = 0, l_n_dense = 0, l_n_light = 0, l_products = 0;
+    long long l_n_s = 0, l_n_t = 0, l_n_l = 0, l_n_m = 0, l_n_w = 0, l_n_g = 0, l_n_dense = 0, l_n_light = 0, l_products = 0, l_dense_entries = 0;
 };
 
 // B in slab order (slab.hip): column windows, entries sorted by window, pieces with links.
@@ -95,6 +95,8 @@ struct spmm_ctx {
     int slab_dense_cols = 15360;    // windows up to this width keep dense accumulators, wider ones the compact form
     long long slab_smax = 4194304;  // entries of B per window (its slab: 10 bytes an entry); fewer, heavier windows measured faster than L2-sized ones
     int dense_sparse = 8192;  // runs of table windows of a dense row with at most this many entries of C are one bitmap window (0 = off)
+    int dense_bounds = 1;     // dense rows read their window bounds from per-row tables in sweep order, gathered from the window table by every numeric call
+    long long dense_bounds_max = 32ll << 30;   // bytes of those tables per call; beyond, the dense kernel reads the window table itself
     int light_two = 1;        // light window rows: two-level windows (a bitmap bit per 32 columns, then a word per touched group)
     int win_dense_over = 1;   // 1024-thread cursor kernel: a table window with more products than a register-resident window takes dense accumulators
     int light_sym = 1;        // symbolic phase of the light window rows on the small two-level workgroups (k_sym2) instead of k_symd

@@ -65,7 +65,9 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
 #ifdef SPMM_DIAG
     if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);   // diagnostic builds only: results are wrong when nonzero
 #endif
-    if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e);   // 1: every window kernel, 2: the 1024-thread cursor kernel only
+    if (const char* e = getenv("SPMM_DENSE_BOUNDS")) c->dense_bounds = atoi(e);
+    if (const char* e = getenv("SPMM_DENSE_BOUNDS_MAX")) c->dense_bounds_max = atoll(e);
+    if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e);   // 1: every window kernel, 2: the 1024-thread cursor kernel only, 3: the 256-thread one only
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
     c->pinned_bytes = 4096;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_
     }
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_N = 14 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_DENSE_ENT = 14, CNT_N = 15 };
 
 // ---------------------------------------------------------------------------
 // P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
@@ -165,15 +165,15 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
     enum { C_NONE = 0, C_G = 1, C_M = 2, C_W = 3, C_L = 4, C_S = 5, C_T = 6, C_DENSE = 7, C_LIGHT = 8, C_N = 9 };
     __shared__ int32_t wcnt[NW][C_N];
     __shared__ long long gbase[C_N];
-    __shared__ long long wprod[NW];
+    __shared__ long long wprod[NW], went[NW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t row = (int64_t)row_beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long p = 0;
-    int cat = C_NONE;
+    int cat = C_NONE, len_a = 0;
     bool dense = false, light = false;
     if (row < row_end) {
         p = prod[row];
-        const int len_a = a_ip[row + 1] - a_ip[row];
+        len_a = a_ip[row + 1] - a_ip[row];
         // the radix expand-sort-compress kernels index the entries of a row with 16 bits
         const bool many_entries = len_a > 65535;
         // Dense rows with very many entries are a long serial chain for one workgroup.  The symbolic call
@@ -216,14 +216,17 @@ __global__ void __launch_bounds__(CLS_THREADS) k_classify(int32_t row_beg, int32
     }
     {
         const long long s = wave_reduce_sum(p);
-        if (lane == 0) wprod[wv] = s;
+        // entries of A in the rows that take the dense kernel (the size of their per-row bound tables)
+        const long long se = wave_reduce_sum((long long)((dense || cat == C_G) ? len_a : 0));
+        if (lane == 0) { wprod[wv] = s; went[wv] = se; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         // one atomic per workgroup: thousands on one word would be the longest part of the kernel
-        long long s = 0;
-        for (int w = 0; w < NW; w++) s += wprod[w];
+        long long s = 0, se = 0;
+        for (int w = 0; w < NW; w++) { s += wprod[w]; se += went[w]; }
         if (s) atomicAdd((unsigned long long*)&counters[CNT_PRODUCTS], (unsigned long long)s);
+        if (se) atomicAdd((unsigned long long*)&counters[CNT_DENSE_ENT], (unsigned long long)se);
     }
     if (threadIdx.x >= C_G && threadIdx.x < C_N) {
         const int c = threadIdx.x;
@@ -1214,6 +1217,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
     const bool single_chunk = lenA <= THREADS;
+    const unsigned long long kern_t0 = (STAMP && tid == 0) ? win_clock() : 0ull;
 
     // base windows per LDS window: about U*THREADS products per window, at most the bitmap width
     int m = (WORDS * 32) >> shift;
@@ -1315,6 +1319,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         for (int i = 0; i < 24; i++) st_lds[i] = 0;
         st_lds[15] = win_clock();
         win_t0 = st_lds[15];
+        st_lds[16] = win_t0 - kern_t0;   // set-up: clearing the arrays and the cumulative table sums
     }
 #define WIN_ARRIVE(k) if (STAMP && lane == 0) st_arr[(k) * NW + wv] = win_clock();
 #define WIN_SKEW(k, slot)                                                        \
@@ -1792,6 +1797,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         for (int i = 0; i < 15; i++) atomicAdd(&stamps[i], st_lds[i]);
     if (STAMP && THREADS == 1024 && NUMERIC && tid == 0)   // the class sums go to the symbolic half of the stamp array (slots 0..7 of it), unused by k_symd
         for (int i = 0; i < 8; i++) atomicAdd(&stamps[i - 16], st_lds[16 + i]);
+    if (STAMP && THREADS == 256 && NUMERIC && tid == 0) {   // small workgroups: set-up cycles, cycles of the whole row, rows
+        atomicAdd(&stamps[-16], st_lds[16]);
+        atomicAdd(&stamps[-15], win_clock() - kern_t0);
+        atomicAdd(&stamps[-14], 1ull);
+    }
     if (!NUMERIC) {
         int tot;
         block_exclusive_scan<THREADS, int32_t>(mycount, tmp, &tot);
@@ -1799,10 +1809,121 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     }
 }
 
+// ---------------------------------------------------------------------------
+// Bound tables of the dense rows.  The dense kernel needs, for every (entry of A, table window) pair of a row, the
+// position in B where the entry's products of that window start.  Read from the window table that is one 4-byte
+// load from a line of the entry's own table row, per pair: the pairs of a row are spread over as many table rows as
+// it has entries, and a 128-byte line serves a handful of windows at best.  A numeric call therefore gathers the
+// bounds of its dense rows once, row by row, into tables of their own: bound[w * lenA + pos] for table window w
+// (0 .. nbase) and the entry at sweep position pos.  The positions follow the sweep order of the dense kernel:
+// entry e belongs to pass e / 1024 and, inside the pass, to wave e % 16 as its lane (e % 1024) / 16; the entries
+// of one wave and pass lie next to each other, so a wave reads 64 consecutive bounds.  A pass of n entries gives
+// wave wv the lanes 0 .. n/16 (+1 for wv < n % 16), which packs the last pass without holes.
+__device__ __forceinline__ int dense_pos(int e, int lenA) {
+    const int c = e >> 10, r = e & 1023, wv = r & 15, el = r >> 4;
+    const int left = lenA - (c << 10);
+    const int n = left < 1024 ? left : 1024;
+    const int q = n >> 4, rm = n & 15;
+    return (c << 10) + wv * q + (wv < rm ? wv : rm) + el;
+}
+__device__ __forceinline__ int dense_entry_at(int pos, int lenA) {   // inverse of dense_pos
+    const int c = pos >> 10, r = pos & 1023;
+    const int left = lenA - (c << 10);
+    const int n = left < 1024 ? left : 1024;
+    const int q = n >> 4, rm = n & 15;
+    const int boundary = rm * (q + 1);
+    int wv, el;
+    if (r < boundary) {
+        wv = r / (q + 1);
+        el = r - wv * (q + 1);
+    } else {   // q > 0 here: with q == 0 every position of the pass lies below the boundary
+        const int r2 = r - boundary;
+        wv = rm + r2 / q;
+        el = r2 - (wv - rm) * q;
+    }
+    return (c << 10) + el * 16 + wv;
+}
+
+// doff[i] = entries of A in the dense rows before list position i (list_g's rows, then the first n_dense of
+// list_w); doff[n_g + n_dense] = all of them.  One workgroup.
+__global__ void __launch_bounds__(1024) k_dense_offsets(const int32_t* __restrict__ list_g, int n_g, const int32_t* __restrict__ list_w,
+                                                        int n_dense, const int32_t* __restrict__ a_ip, int64_t* __restrict__ doff) {
+    __shared__ int64_t tmp[1024 / 64 + 1];
+    const int n = n_g + n_dense;
+    int64_t run = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + (int)threadIdx.x;
+        int64_t v = 0;
+        if (i < n) {
+            const int row = i < n_g ? list_g[i] : list_w[i - n_g];
+            v = a_ip[row + 1] - a_ip[row];
+        }
+        int64_t tot;
+        const int64_t ex = block_exclusive_scan<1024, int64_t>(v, tmp, &tot);
+        if (i < n) doff[i] = run + ex;
+        run += tot;
+    }
+    if (threadIdx.x == 0) doff[n] = run;
+}
+
+// Gathers the bound tables: a workgroup takes 64 consecutive sweep positions of the concatenated dense rows, reads
+// their table rows 64 windows at a time (a wave per table row: 256 consecutive bytes) and writes them window by
+// window (a wave per window: the 64 positions next to each other) through an LDS tile.
+__global__ void __launch_bounds__(256) k_dense_bounds(const int32_t* __restrict__ list_g, int n_g, const int32_t* __restrict__ list_w,
+                                                      int n_dense, const int32_t* __restrict__ a_ip, const int32_t* __restrict__ a_ix,
+                                                      const double* __restrict__ a_val, const int32_t* __restrict__ winptr, int nbase,
+                                                      const int64_t* __restrict__ doff, int32_t* __restrict__ dbound, double* __restrict__ dav) {
+    __shared__ int32_t tile[64][65];
+    __shared__ int32_t krow[64], dlen[64];
+    __shared__ int64_t dst[64];
+    const int n = n_g + n_dense;
+    const int64_t total = doff[n];
+    const int64_t tstride = (int64_t)nbase + 1;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    if (tid < 64) {
+        const int64_t p = (int64_t)blockIdx.x * 64 + tid;
+        int k = -1, ln = 0;
+        int64_t d = 0;
+        if (p < total) {
+            int lo = 0, hi = n;   // doff[lo] <= p < doff[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (doff[mid] <= p) lo = mid; else hi = mid;
+            }
+            const int row = lo < n_g ? list_g[lo] : list_w[lo - n_g];
+            const int a0 = a_ip[row];
+            ln = a_ip[row + 1] - a0;
+            const int pos = (int)(p - doff[lo]);
+            const int e = dense_entry_at(pos, ln);
+            k = a_ix[a0 + e];
+            d = doff[lo] * tstride + pos;
+            dav[p] = a_val[a0 + e];   // the entries' values in the same order
+        }
+        krow[tid] = k;
+        dlen[tid] = ln;
+        dst[tid] = d;
+    }
+    __syncthreads();
+    const int kl = krow[lane], ln = dlen[lane];
+    const int64_t d = dst[lane];
+    for (int w0 = 0; w0 <= nbase; w0 += 64) {
+        for (int j = g; j < 64; j += 4) {
+            const int k = krow[j], w = w0 + lane;
+            tile[j][lane] = (k >= 0 && w <= nbase) ? winptr[(int64_t)k * tstride + w] : 0;
+        }
+        __syncthreads();
+        for (int wl = g; wl < 64; wl += 4) {
+            const int w = w0 + wl;
+            if (kl >= 0 && w <= nbase) dbound[d + (int64_t)w * ln] = tile[lane][wl];
+        }
+        __syncthreads();
+    }
+}
+
 #ifndef DENSE_TQ
 #define DENSE_TQ 4
 #endif
-template <int THREADS, bool STAMP>
+template <int THREADS, bool STAMP, bool LB>
 __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                    const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                    const uint32_t* __restrict__ b12,
@@ -1812,7 +1933,8 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    unsigned long long* __restrict__ stamps, const int32_t* __restrict__ list_g,
                                                    int n_shared, int ntask_shared, int chunk,
                                                    const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt, int major_rows,
-                                                   int sparse_max) {
+                                                   int sparse_max, const int32_t* __restrict__ dbound, const double* __restrict__ dav,
+                                                   const int64_t* __restrict__ doff_g, const int64_t* __restrict__ doff_w) {
     // The first n_shared workgroups work on the rows of list_g, ntask_shared workgroups per row: workgroup
     // t of a row takes the table windows t, t + ntask, ... (in chunks of `chunk`) and finds the place of a
     // window's entries in the row of C from the per-window counts of the symbolic phase (at most THREADS
@@ -1837,11 +1959,20 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // major_rows > 0: the workgroups of one chunk of windows are neighbours in the grid (all rows, then the next chunk)
     const int task = !shared ? 0 : major_rows > 0 ? (int)(blockIdx.x / (unsigned)major_rows) : (int)(blockIdx.x % (unsigned)ntask);
-    const int row = !shared ? list[blockIdx.x - (unsigned)n_shared]
-                            : list_g[major_rows > 0 ? blockIdx.x % (unsigned)major_rows : blockIdx.x / (unsigned)ntask];
+    const int li = !shared ? (int)(blockIdx.x - (unsigned)n_shared)
+                           : (int)(major_rows > 0 ? blockIdx.x % (unsigned)major_rows : blockIdx.x / (unsigned)ntask);   // place in its list
+    const int row = !shared ? list[li] : list_g[li];
     const int a0 = a_ip[row];
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
+    // LB: the row's own bound table, bound[w * lenA + dense_pos(entry)]
+    const int32_t* Lrow = nullptr;
+    const double* Arow = nullptr;   // the entries' values by sweep position
+    if constexpr (LB) {
+        const int64_t o = shared ? doff_g[li] : doff_w[li];
+        Lrow = dbound + o * tstride;
+        Arow = dav + o;
+    }
     // E entries per wave and pass; entry (pass c, lane el) of wave wv is (c*E + el)*NW + wv, so the
     // long rows of B that cluster at low column ids spread over all waves
     const int lgE = dbg ? dbg : lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
@@ -1880,10 +2011,18 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
         const int e = el * NW + wv;
         have = e < lenA;
         if (have) {
-            Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
-            av = a_val[a0 + e];
-            t_cur = Tp[w_first];
-            t_nxt = Tp[w_first + 1];
+            if constexpr (LB) {
+                const int pos = dense_pos(e, lenA);
+                av = Arow[pos];
+                Tp = Lrow + pos;
+                t_cur = Tp[(int64_t)w_first * lenA];
+                t_nxt = Tp[(int64_t)(w_first + 1) * lenA];
+            } else {
+                av = a_val[a0 + e];
+                Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                t_cur = Tp[w_first];
+                t_nxt = Tp[w_first + 1];
+            }
         }
         if (pipelined) {
             // unconditional loads (position 0 when there is no such product): the compiler can then count
@@ -1926,10 +2065,18 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 const int e = (c * 64 + lane) * NW + wv;
                 s_ = 0; len_ = 0; a_ = 0.0;
                 if (e < lenA) {
-                    const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
-                    s_ = Tq[w_first];
-                    len_ = Tq[w_end] - s_;
-                    a_ = a_val[a0 + e];
+                    if constexpr (LB) {
+                        const int pos = dense_pos(e, lenA);
+                        const int32_t* Tq = Lrow + pos;
+                        s_ = Tq[(int64_t)w_first * lenA];
+                        len_ = Tq[(int64_t)w_end * lenA] - s_;
+                        a_ = Arow[pos];
+                    } else {
+                        const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                        s_ = Tq[w_first];
+                        len_ = Tq[w_end] - s_;
+                        a_ = a_val[a0 + e];
+                    }
                 }
             };
             if (npass_s == 1) entry(0, s1, len1, a1);
@@ -2005,7 +2152,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             if (tph == 0 && have) {
 #pragma unroll
                 for (int j = 0; j < DENSE_TQ; j++)
-                    if (w + 2 + j <= nbase) tq[j] = Tp[w + 2 + j];
+                    if (w + 2 + j <= nbase) tq[j] = LB ? Tp[(int64_t)(w + 2 + j) * lenA] : Tp[w + 2 + j];
             }
 #pragma unroll
             for (int j = 0; j < DENSE_TQ; j++)
@@ -2021,10 +2168,18 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     const int e = ((c << lgE) + el) * NW + wv;
                     len = 0;
                     if (e < lenA) {
-                        const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
-                        s = Tq[w];
-                        len = Tq[w + 1] - s;
-                        a = a_val[a0 + e];
+                        if constexpr (LB) {
+                            const int pos = dense_pos(e, lenA);
+                            const int32_t* Tq = Lrow + pos;
+                            s = Tq[(int64_t)w * lenA];
+                            len = Tq[(int64_t)(w + 1) * lenA] - s;
+                            a = Arow[pos];
+                        } else {
+                            const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                            s = Tq[w];
+                            len = Tq[w + 1] - s;
+                            a = a_val[a0 + e];
+                        }
                     }
                 }
                 if (__ballot(len > 0) == 0ull) continue;   // nothing of this wave's entries falls into the window
@@ -2659,6 +2814,7 @@ struct Bins {
     uint32_t* wcnt;      // [slot][table window] entries of C, written by the symbolic kernel
     long long n_light;   // the last n_light rows of list_w have at most light_max products
     long long n_s, n_t, n_l, n_m, n_w, n_g, n_dense, products;   // the first n_dense rows of list_w take the dense kernel
+    long long dense_entries;   // entries of A in the rows of the dense kernel (list_g and the first n_dense of list_w)
     int32_t* winptr;
     int shift, nbase;
     uint32_t* b12;       // numeric: B as 12-byte {column id, value} records for the window kernels
@@ -2806,10 +2962,12 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         out->n_light = h[CNT_LIGHT];
         out->n_g = h[CNT_GIANT];
         out->products = h[CNT_PRODUCTS];
+        out->dense_entries = h[CNT_DENSE_ENT];
         if (giant_mode == 1) pc.n_giant = (int)h[CNT_GIANT_ALL];
     } else {
         out->n_s = pc.l_n_s; out->n_t = pc.l_n_t; out->n_l = pc.l_n_l; out->n_m = pc.l_n_m; out->n_w = pc.l_n_w;
         out->n_dense = pc.l_n_dense; out->n_light = pc.l_n_light; out->n_g = pc.l_n_g; out->products = pc.l_products;
+        out->dense_entries = pc.l_dense_entries;
     }
     out->nslots = pc.n_giant;
     const unsigned long long dig_a = (unsigned long long)h[CNT_DIG_A], dig_b = (unsigned long long)h[CNT_DIG_B];
@@ -2870,6 +3028,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     pc.l_row_beg = row_beg; pc.l_row_end = row_end;
     pc.l_n_s = out->n_s; pc.l_n_t = out->n_t; pc.l_n_l = out->n_l; pc.l_n_m = out->n_m; pc.l_n_w = out->n_w; pc.l_n_g = out->n_g;
     pc.l_n_dense = out->n_dense; pc.l_n_light = out->n_light; pc.l_products = out->products;
+    pc.l_dense_entries = out->dense_entries;
     HIPCHK(hipGetLastError());
     return SPMM_OK;
 }
@@ -2891,7 +3050,7 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
-    auto kern = (ctx->win_stamps == 1 || (ctx->win_stamps == 2 && THREADS == 1024)) ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true, TWO>
+    auto kern = (ctx->win_stamps == 1 || (ctx->win_stamps == 2 && THREADS == 1024) || (ctx->win_stamps == 3 && THREADS == 256)) ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true, TWO>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false, TWO>;
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for_row_slices(ctx, bins.n_w, THREADS, 1, [&](long long off, long long cnt) {
@@ -2926,7 +3085,25 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
         static_assert(dl <= 160 * 1024, "LDS budget of one CU");
-        auto kd = ctx->win_stamps == 1 ? k_dense<1024, true> : k_dense<1024, false>;
+        // bound tables of this call's dense rows (window w of a row of lenA entries is w * lenA 32-bit indices away)
+        const long long nd_rows = bins.n_g + bins.n_dense;
+        const size_t lb_elems = (size_t)bins.dense_entries * ((size_t)bins.nbase + 1);
+        const bool lb = ctx->dense_bounds != 0 && bins.dense_entries > 0 && lb_elems * 4 <= (size_t)ctx->dense_bounds_max && nd_rows < 0x7fffffffll;
+        int32_t* dbound = nullptr;
+        int64_t* doff = nullptr;
+        double* dav = nullptr;
+        if (lb) {
+            CHK(ws(ctx, WS_DBOUND, lb_elems + 1, &dbound));
+            CHK(ws(ctx, WS_DAVAL, (size_t)bins.dense_entries + 1, &dav));
+            CHK(ws(ctx, WS_DOFF, (size_t)nd_rows + 1, &doff));
+            hipLaunchKernelGGL(k_dense_offsets, dim3(1), dim3(1024), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w, (int)bins.n_dense,
+                               A->indptr, doff);
+            const long long tiles = (bins.dense_entries + 63) / 64;
+            hipLaunchKernelGGL(k_dense_bounds, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w,
+                               (int)bins.n_dense, A->indptr, A->indices, A->data, bins.winptr, bins.nbase, doff, dbound, dav);
+        }
+        auto kd = ctx->win_stamps == 1 ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
+                                       : (lb ? k_dense<1024, false, true> : k_dense<1024, false, false>);
         unsigned long long* stamps;
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
@@ -2940,7 +3117,8 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                                A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
                                c_val, ctx->win_dbg >> 8, stamps, list_g, n_shared, gtasks, gchunk,
                                bins.gslot, bins.wcnt, major ? (int)n_g : 0,
-                               ctx->dense_sparse < DENSE_SPARSE_VALS ? ctx->dense_sparse : DENSE_SPARSE_VALS);
+                               ctx->dense_sparse < DENSE_SPARSE_VALS ? ctx->dense_sparse : DENSE_SPARSE_VALS, dbound, dav,
+                               lb ? doff + (list_g - bins.list_g) : nullptr, lb ? doff + bins.n_g + (list_w - bins.list_w) : nullptr);
         };
         const long long max_wg = ctx->max_grid_threads / 1024 > 0 ? ctx->max_grid_threads / 1024 : 1;
         if (bins.n_g * gtasks + bins.n_dense <= max_wg) launch(bins.list_g, bins.n_g, bins.list_w, bins.n_dense);
