@@ -1268,13 +1268,28 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     if (NUMERIC && adaptive) {
         for (int j = tid; j <= nh; j += THREADS) cs[j] = 0u;
         __syncthreads();
-        for (int jb = 0; jb <= nh; jb += 64) {
-            const int j = jb + lane;
-            const int wj = j * gsz < nbase ? j * gsz : nbase;
-            uint32_t sum = 0;
-            if (j <= nh)
-                for (int e = wv; e < lenA; e += NW) sum += (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + wj];
-            if (j <= nh && sum) atomicAdd(&cs[j], sum);
+        // (entry, granule) pairs dealt to the waves 64 granules of one entry at a time, eight loads in flight per
+        // lane: a loop over the entries with one load per turn is a chain of memory round trips, a tenth of the
+        // kernel's time for rows of a few entries
+        constexpr int CSU = 8;
+        const int gw = (nh + 64) & ~63;   // granule slots per entry (0 .. nh, padded to whole waves)
+        const int npairs = lenA * gw;
+        for (int p0 = wv * 64; p0 < npairs; p0 += THREADS * CSU) {
+            uint32_t v[CSU];
+            int jj[CSU];
+#pragma unroll
+            for (int q = 0; q < CSU; q++) {
+                const int p = p0 + q * THREADS;   // wave-uniform
+                const int e = p / gw;
+                const int j = p - e * gw + lane;
+                const bool ok = p < npairs && j <= nh;
+                const int wj = j * gsz < nbase ? j * gsz : nbase;
+                v[q] = ok ? (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + wj] : 0u;
+                jj[q] = j;
+            }
+#pragma unroll
+            for (int q = 0; q < CSU; q++)
+                if (v[q]) atomicAdd(&cs[jj[q]], v[q]);
         }
         __syncthreads();
     }
@@ -2548,12 +2563,27 @@ __global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restric
     // are a difference of two of them
     for (int j = tid; j <= nbase; j += THREADS) cs[j] = 0u;
     __syncthreads();
-    for (int jb = 0; jb <= nbase; jb += 64) {
-        const int j = jb + lane;
-        uint32_t sum = 0;
-        if (j <= nbase)
-            for (int e = wv; e < lenA; e += NW) sum += (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + j];
-        if (j <= nbase && sum) atomicAdd(&cs[j], sum);
+    {
+        // (entry, table window) pairs dealt to the waves 64 windows of one entry at a time, eight loads in flight per lane
+        constexpr int CSU = 8;
+        const int gw = (nbase + 64) & ~63;   // window slots per entry (0 .. nbase, padded to whole waves)
+        const int npairs = lenA * gw;
+        for (int p0 = wv * 64; p0 < npairs; p0 += THREADS * CSU) {
+            uint32_t v[CSU];
+            int jj[CSU];
+#pragma unroll
+            for (int q = 0; q < CSU; q++) {
+                const int p = p0 + q * THREADS;   // wave-uniform
+                const int e = p / gw;
+                const int j = p - e * gw + lane;
+                const bool ok = p < npairs && j <= nbase;
+                v[q] = ok ? (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + j] : 0u;
+                jj[q] = j;
+            }
+#pragma unroll
+            for (int q = 0; q < CSU; q++)
+                if (v[q]) atomicAdd(&cs[jj[q]], v[q]);
+        }
     }
     __syncthreads();
     // widest window in table windows: two-level windows of a single-chunk row, plain windows in `fine` otherwise
