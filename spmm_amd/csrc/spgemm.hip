@@ -1887,12 +1887,14 @@ __global__ void __launch_bounds__(1024) k_dense_offsets(const int32_t* __restric
 __global__ void __launch_bounds__(256) k_dense_bounds(const int32_t* __restrict__ list_g, int n_g, const int32_t* __restrict__ list_w,
                                                       int n_dense, const int32_t* __restrict__ a_ip, const int32_t* __restrict__ a_ix,
                                                       const double* __restrict__ a_val, const int32_t* __restrict__ winptr, int nbase,
-                                                      const int64_t* __restrict__ doff, int32_t* __restrict__ dbound, double* __restrict__ dav) {
+                                                      const int64_t* __restrict__ doff, int i0, int i1, int32_t* __restrict__ dbound,
+                                                      double* __restrict__ dav) {
+    // list positions [i0, i1): their tables start at dbound[0], their values at dav[0]
     __shared__ int32_t tile[64][65];
     __shared__ int32_t krow[64], dlen[64];
     __shared__ int64_t dst[64];
-    const int n = n_g + n_dense;
-    const int64_t total = doff[n];
+    const int64_t base = doff[i0];
+    const int64_t total = doff[i1] - base;
     const int64_t tstride = (int64_t)nbase + 1;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     if (tid < 64) {
@@ -1900,18 +1902,18 @@ __global__ void __launch_bounds__(256) k_dense_bounds(const int32_t* __restrict_
         int k = -1, ln = 0;
         int64_t d = 0;
         if (p < total) {
-            int lo = 0, hi = n;   // doff[lo] <= p < doff[hi]
+            int lo = i0, hi = i1;   // doff[lo] - base <= p < doff[hi] - base
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (doff[mid] <= p) lo = mid; else hi = mid;
+                if (doff[mid] - base <= p) lo = mid; else hi = mid;
             }
             const int row = lo < n_g ? list_g[lo] : list_w[lo - n_g];
             const int a0 = a_ip[row];
             ln = a_ip[row + 1] - a0;
-            const int pos = (int)(p - doff[lo]);
+            const int pos = (int)(p - (doff[lo] - base));
             const int e = dense_entry_at(pos, ln);
             k = a_ix[a0 + e];
-            d = doff[lo] * tstride + pos;
+            d = (doff[lo] - base) * tstride + pos;
             dav[p] = a_val[a0 + e];   // the entries' values in the same order
         }
         krow[tid] = k;
@@ -1949,7 +1951,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                                                    int n_shared, int ntask_shared, int chunk,
                                                    const int32_t* __restrict__ gslot, const uint32_t* __restrict__ wcnt, int major_rows,
                                                    int sparse_max, const int32_t* __restrict__ dbound, const double* __restrict__ dav,
-                                                   const int64_t* __restrict__ doff_g, const int64_t* __restrict__ doff_w) {
+                                                   const int64_t* __restrict__ doff_g, const int64_t* __restrict__ doff_w, int64_t dbase) {
     // The first n_shared workgroups work on the rows of list_g, ntask_shared workgroups per row: workgroup
     // t of a row takes the table windows t, t + ntask, ... (in chunks of `chunk`) and finds the place of a
     // window's entries in the row of C from the per-window counts of the symbolic phase (at most THREADS
@@ -1984,7 +1986,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     const int32_t* Lrow = nullptr;
     const double* Arow = nullptr;   // the entries' values by sweep position
     if constexpr (LB) {
-        const int64_t o = shared ? doff_g[li] : doff_w[li];
+        const int64_t o = (shared ? doff_g[li] : doff_w[li]) - dbase;   // dbase: where the tables of this launch's group start
         Lrow = dbound + o * tstride;
         Arow = dav + o;
     }
@@ -3115,49 +3117,85 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         int phd = phase_begin(ctx, SPMM_PH_DENSE_NUM);
         constexpr size_t dl = dense_lds_bytes(1024);
         static_assert(dl <= 160 * 1024, "LDS budget of one CU");
-        // bound tables of this call's dense rows (window w of a row of lenA entries is w * lenA 32-bit indices away)
+        // Bound tables of this call's dense rows (window w of a row of lenA entries is w * lenA 32-bit indices away),
+        // for groups of consecutive list positions whose tables fit the budget: most calls are one group.
+        struct dense_group { long long i0, i1; int64_t base, entries; bool lb; };
+        std::vector<dense_group> groups;
         const long long nd_rows = bins.n_g + bins.n_dense;
-        const size_t lb_elems = (size_t)bins.dense_entries * ((size_t)bins.nbase + 1);
-        const bool lb = ctx->dense_bounds != 0 && bins.dense_entries > 0 && lb_elems * 4 <= (size_t)ctx->dense_bounds_max && nd_rows < 0x7fffffffll;
+        const size_t wpr = (size_t)bins.nbase + 1;
+        const size_t budget_entries = ctx->dense_bounds_max > 0 ? (size_t)ctx->dense_bounds_max / (4 * wpr) : 0;
         int32_t* dbound = nullptr;
         int64_t* doff = nullptr;
         double* dav = nullptr;
-        if (lb) {
-            CHK(ws(ctx, WS_DBOUND, lb_elems + 1, &dbound));
-            CHK(ws(ctx, WS_DAVAL, (size_t)bins.dense_entries + 1, &dav));
+        if (ctx->dense_bounds != 0 && bins.dense_entries > 0 && budget_entries > 0 && nd_rows < 0x7fffffffll) {
             CHK(ws(ctx, WS_DOFF, (size_t)nd_rows + 1, &doff));
             hipLaunchKernelGGL(k_dense_offsets, dim3(1), dim3(1024), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w, (int)bins.n_dense,
                                A->indptr, doff);
-            const long long tiles = (bins.dense_entries + 63) / 64;
-            hipLaunchKernelGGL(k_dense_bounds, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w,
-                               (int)bins.n_dense, A->indptr, A->indices, A->data, bins.winptr, bins.nbase, doff, dbound, dav);
-        }
-        auto kd = ctx->win_stamps == 1 ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
-                                       : (lb ? k_dense<1024, false, true> : k_dense<1024, false, false>);
+            size_t most = 0;
+            if ((size_t)bins.dense_entries <= budget_entries) {
+                groups.push_back({0, nd_rows, 0, (int64_t)bins.dense_entries, true});
+                most = (size_t)bins.dense_entries;
+            } else {
+                std::vector<int64_t> h((size_t)nd_rows + 1);
+                HIPCHK(hipMemcpyAsync(h.data(), doff, sizeof(int64_t) * ((size_t)nd_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                for (long long i0 = 0; i0 < nd_rows;) {
+                    long long i1 = i0;
+                    while (i1 < nd_rows && (size_t)(h[i1 + 1] - h[i0]) <= budget_entries) i1++;
+                    if (i1 == i0) {   // a single row beyond the budget reads the window table itself
+                        groups.push_back({i0, i0 + 1, 0, 0, false});
+                        i0++;
+                    } else {
+                        groups.push_back({i0, i1, h[i0], h[i1] - h[i0], true});
+                        if ((size_t)(h[i1] - h[i0]) > most) most = (size_t)(h[i1] - h[i0]);
+                        i0 = i1;
+                    }
+                }
+            }
+            if (most > 0) {
+                CHK(ws(ctx, WS_DBOUND, most * wpr + 1, &dbound));
+                CHK(ws(ctx, WS_DAVAL, most + 1, &dav));
+            }
+        } else groups.push_back({0, nd_rows, 0, 0, false});
         unsigned long long* stamps;
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
-        HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
         // rows with very many entries first, each shared by giant_tasks workgroups
         const bool major = ctx->giant_major && bins.nbase >= 2 * ctx->major_chunk;
         const int gchunk = major ? ctx->major_chunk : ctx->giant_chunk;
         const int gtasks = major ? (bins.nbase + gchunk - 1) / gchunk : ctx->giant_tasks;
-        auto launch = [&](const int32_t* list_g, long long n_g, const int32_t* list_w, long long n_dense) {
-            const int n_shared = (int)(n_g * gtasks);
-            hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + n_dense)), dim3(1024), dl, ctx->stream, list_w, A->indptr,
-                               A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
-                               c_val, ctx->win_dbg >> 8, stamps, list_g, n_shared, gtasks, gchunk,
-                               bins.gslot, bins.wcnt, major ? (int)n_g : 0,
-                               ctx->dense_sparse < DENSE_SPARSE_VALS ? ctx->dense_sparse : DENSE_SPARSE_VALS, dbound, dav,
-                               lb ? doff + (list_g - bins.list_g) : nullptr, lb ? doff + bins.n_g + (list_w - bins.list_w) : nullptr);
-        };
         const long long max_wg = ctx->max_grid_threads / 1024 > 0 ? ctx->max_grid_threads / 1024 : 1;
-        if (bins.n_g * gtasks + bins.n_dense <= max_wg) launch(bins.list_g, bins.n_g, bins.list_w, bins.n_dense);
-        else {
-            // more workgroups than one grid dimension holds: the shared rows in slices, then the others
-            const long long per = max_wg / gtasks > 0 ? max_wg / gtasks : 1;
-            for (long long off = 0; off < bins.n_g; off += per)
-                launch(bins.list_g + off, bins.n_g - off < per ? bins.n_g - off : per, bins.list_w, 0);
-            for_row_slices(ctx, bins.n_dense, 1024, 1, [&](long long off, long long cnt) { launch(bins.list_g, 0, bins.list_w + off, cnt); });
+        for (const dense_group& gr : groups) {
+            const bool lb = gr.lb;
+            if (lb) {
+                const long long tiles = (gr.entries + 63) / 64;
+                hipLaunchKernelGGL(k_dense_bounds, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w,
+                                   (int)bins.n_dense, A->indptr, A->indices, A->data, bins.winptr, bins.nbase, doff, (int)gr.i0, (int)gr.i1,
+                                   dbound, dav);
+            }
+            auto kd = ctx->win_stamps == 1 ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
+                                           : (lb ? k_dense<1024, false, true> : k_dense<1024, false, false>);
+            HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
+            auto launch = [&](const int32_t* list_g, long long n_g, const int32_t* list_w, long long n_dense) {
+                const int n_shared = (int)(n_g * gtasks);
+                hipLaunchKernelGGL(kd, dim3((unsigned)(n_shared + n_dense)), dim3(1024), dl, ctx->stream, list_w, A->indptr,
+                                   A->indices, A->data, bins.b12, bins.winptr, bins.nbase, bins.shift, c_ip, row_beg, c_ix,
+                                   c_val, ctx->win_dbg >> 8, stamps, list_g, n_shared, gtasks, gchunk,
+                                   bins.gslot, bins.wcnt, major ? (int)n_g : 0,
+                                   ctx->dense_sparse < DENSE_SPARSE_VALS ? ctx->dense_sparse : DENSE_SPARSE_VALS, dbound, dav,
+                                   lb ? doff + (list_g - bins.list_g) : nullptr, lb ? doff + bins.n_g + (list_w - bins.list_w) : nullptr,
+                                   gr.base);
+            };
+            // the group's part of list_g and of list_w
+            const long long g0 = gr.i0 < bins.n_g ? gr.i0 : bins.n_g, g1 = gr.i1 < bins.n_g ? gr.i1 : bins.n_g;
+            const long long w0 = (gr.i0 > bins.n_g ? gr.i0 : bins.n_g) - bins.n_g, w1 = (gr.i1 > bins.n_g ? gr.i1 : bins.n_g) - bins.n_g;
+            if ((g1 - g0) * gtasks + (w1 - w0) <= max_wg) launch(bins.list_g + g0, g1 - g0, bins.list_w + w0, w1 - w0);
+            else {
+                // more workgroups than one grid dimension holds: the shared rows in slices, then the others
+                const long long per = max_wg / gtasks > 0 ? max_wg / gtasks : 1;
+                for (long long off = g0; off < g1; off += per)
+                    launch(bins.list_g + off, g1 - off < per ? g1 - off : per, bins.list_w, 0);
+                for_row_slices(ctx, w1 - w0, 1024, 1, [&](long long off, long long cnt) { launch(bins.list_g, 0, bins.list_w + w0 + off, cnt); });
+            }
         }
         phase_end(ctx, phd);
         bins.list_w += bins.n_dense;

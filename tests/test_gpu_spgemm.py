@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 # with 2^15-column table windows), and the cursor kernel for the symbolic phase with fixed-width
 # numeric windows; rows of more than 8 entries shared by several workgroups of the dense kernel; dense rows cut into
 # runs of 4 table windows, one workgroup each (runs with few entries of C as one bitmap window: by default up to 8192
-# entries, never, and up to 200 so that both forms meet in one row); every window
+# entries, never, and up to 200 so that both forms meet in one row); the dense kernel reading its window bounds from
+# the window table instead of per-row bound tables, and with the bound tables built for a few rows at a time (a
+# budget of some thousand bytes: rows beyond it read the window table); every window
 # row of at most 65535 products through the 256-thread cursor workgroups (16-bit rank prefixes), with two-level
 # windows (a bitmap bit per 32 columns) and with plain ones; the 1024-thread cursor kernel with two cursor sweeps
 # instead of dense accumulators for a table window that overfills a register-resident window; the sorting kernels for rows of up to 8192 products (the
@@ -35,6 +37,9 @@ PLANS = {
     "dense_window_major_mixed_runs": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_SPARSE": "200"},
     "dense_window_major_runs_of_16": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "16"},
     "sliced_launches": {"SPMM_MAX_GRID_THREADS": "8192", "SPMM_DENSE_MIN": "1"},
+    "dense_bounds_from_window_table": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_BOUNDS": "0"},
+    "dense_bounds_in_small_groups": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_BOUNDS_MAX": "6000"},
+    "dense_bounds_in_small_groups_sliced": {"SPMM_DENSE_MIN": "1", "SPMM_MAX_GRID_THREADS": "8192", "SPMM_DENSE_BOUNDS_MAX": "20000"},
     "slab": {"SPMM_SLAB": "1"},
     "slab_small_windows": {"SPMM_SLAB": "1", "SPMM_SLAB_WMAX": "4096", "SPMM_SLAB_SMAX": "2048", "SPMM_SLAB_DENSE_COLS": "1024",
                            "SPMM_SLAB_THREADS": "256"},
