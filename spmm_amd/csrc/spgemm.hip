@@ -2530,36 +2530,36 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 }
 
 // ---------------------------------------------------------------------------
-// Symbolic phase of the light window rows: 256-thread workgroups of 26 KB, six per CU, with the two-level windows of
-// the numeric light kernel.  A row of few products in a wide matrix costs k_symd a fixed price per 2^20 columns
-// (a pass over all entries and a count over the 128 KB bitmap); here a window is cut by its S2_CAP products: the
-// products go to registers and set one bit per group of 32 columns, every touched group gets a word of `fine` in
-// group order (rank prefix over the group bitmap), the products set their column's bit there, and the row's count
-// is the number of bits in the fine words.  A window that the products of one table window overfill, and every
-// window of a row with more than 256 entries, uses `fine` as a plain bitmap over at most 2^16 columns and reads
-// its products through the directory cursor instead.
-constexpr int S2_THREADS = 256, S2_WORDS = 1024, S2_U = 8, S2_CAP = S2_U * S2_THREADS;
-__global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+// Symbolic phase of the light window rows: 256-thread workgroups of 28 KB, five per CU.  A row of few products in
+// a wide matrix costs k_symd a fixed price per 2^20 columns (a pass over all entries and a count over the 128 KB
+// bitmap); here a window is cut by its S2_CAP products, whatever its width: the products go to registers and their
+// columns into a hash set of S2_TAB slots (linear probing, compare-and-swap on LDS; the set is at most half
+// full), and the row's count is the number of insertions that found an empty slot.  No ranks are needed to count,
+// so a window has three barriers (two for the directory that maps a product to its place in B, one before the set
+// is cleared) where a bitmap with rank prefixes has six.  A window that the products of one table window overfill,
+// and every window of a row with more than 256 entries, uses the set's first S2_CAP words as a plain bitmap over at
+// most 2^16 columns and reads its products through the directory cursor instead.
+constexpr int S2_THREADS = 256, S2_U = 8, S2_CAP = S2_U * S2_THREADS, S2_TAB = 2 * S2_CAP, S2_TAB_LOG2 = 12;
+static_assert(S2_TAB == 1 << S2_TAB_LOG2, "the hash takes the top bits of a 32-bit product");
+__global__ void __launch_bounds__(S2_THREADS, 5) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                         const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
                                                         const int32_t* __restrict__ winptr, int nbase, int shift,
                                                         int32_t* __restrict__ rowcnt) {
     constexpr int THREADS = S2_THREADS, NW = THREADS / 64, U = S2_U;
-    static_assert(U == 8, "eight 16-bit marks and eight fine words per thread move as 16-byte pieces");
-    __shared__ __align__(16) uint32_t coarse[S2_WORDS];
-    __shared__ __align__(16) uint16_t cpre[S2_WORDS];
-    __shared__ __align__(16) uint32_t fine[S2_CAP];
+    static_assert(U == 8, "eight 16-bit marks per thread move as one 16-byte piece");
+    __shared__ __align__(16) uint32_t tab[S2_TAB];   // hash set of (column - first column of the window + 1), 0 = empty
+    uint32_t* const fine = tab;                       // plain bitmap of the windows that do not take the set
     __shared__ __align__(16) uint16_t emap[S2_CAP];
     __shared__ int2 dirs[2][THREADS + 1];
     __shared__ uint32_t cs[1026];
-    __shared__ int32_t tmp_a[NW + 1], tmp_b[NW + 1], tmp_c[NW + 1], wave_ent[NW], total_cnt;
+    __shared__ int32_t tmp_a[NW + 1], tmp_c[NW + 1], wave_ent[NW], total_cnt;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = list[blockIdx.x];
     const int a0 = a_ip[row];
     const int lenA = a_ip[row + 1] - a0;
     const int64_t tstride = (int64_t)nbase + 1;
     const bool single = lenA <= THREADS;
-    for (int i = tid; i < S2_WORDS; i += THREADS) coarse[i] = 0u;
-    for (int i = tid; i < S2_CAP; i += THREADS) fine[i] = 0u;
+    for (int i = tid; i < S2_TAB; i += THREADS) tab[i] = 0u;
     if (tid == 0) total_cnt = 0;
     // cs[j] = sum over the row's entries of the table value at window j: the products of a range of table windows
     // are a difference of two of them
@@ -2588,9 +2588,9 @@ __global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restric
         }
     }
     __syncthreads();
-    // widest window in table windows: two-level windows of a single-chunk row, plain windows in `fine` otherwise
-    const int g2 = (S2_WORDS * 1024) >> shift;
-    const int gmax = single ? (g2 < 256 ? g2 : 256) : ((S2_CAP * 32) >> shift);
+    // widest window in table windows: what the search below covers for the hash set of a single-chunk row, what the
+    // plain bitmap covers otherwise
+    const int gmax = single ? 256 : ((S2_CAP * 32) >> shift);
     auto window_end = [&](int w0) {
         // a window of k table windows fits (monotone in k): lanes try 4, 8, .. 256, then three lanes the ones between
         const uint32_t base = cs[w0];
@@ -2629,7 +2629,7 @@ __global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restric
         if (prod_w == 0u) continue;   // block-uniform
         const int wbase = w0 << shift;
         if (single && prod_w <= (uint32_t)S2_CAP) {
-            // ---- two-level window, products in registers ------------------------------------------------------
+            // ---- hash set of the window's columns, products in registers ---------------------------------------
             // the directory alternates between two buffers, so its build needs no barrier in front
             flip ^= 1;
             int2* dir = dirs[flip];
@@ -2646,9 +2646,7 @@ __global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restric
             __syncthreads();
             const int p_lo = wv * (U * 64);
             const int p_hi = p_lo + U * 64 < Tc ? p_lo + U * 64 : Tc;
-            const bool active = p_lo < p_hi;   // wave-uniform
-            int cc[U];
-            if (active) {
+            if (p_lo < p_hi) {   // wave-uniform
                 // running maximum of the marks over the slice = entry (+1) of every product
                 uint4* mine = (uint4*)(emap + p_lo + lane * U);
                 const uint4 raw = *mine;
@@ -2669,64 +2667,34 @@ __global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restric
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const int p = p_lo + j * 64 + lane;
-                    const int pc = p < p_hi ? p : p_hi - 1;   // lanes past the end repeat the slice's last product
+                    const int pc = p < p_hi ? p : p_hi - 1;   // lanes past the end repeat the slice's last product: found in the set
                     const int2 d = dir[(int)emap[pc] - 1];
                     pos[j] = d.y + (pc - d.x);
                 }
+                uint32_t key[U], h[U], old[U];
 #pragma unroll
-                for (int j = 0; j < U; j++) cc[j] = b_ix[pos[j]] - wbase;
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const int g = cc[j] >> 5;
-                    atomicOr(&coarse[g >> 5], 1u << (g & 31));
-                }
-            }
-            __syncthreads();
-            // rank prefix over the group bitmap: thread t owns words [wpt*t, wpt*t + wpt)
-            const int nwords = (((w1 - w0) << shift) + 1023) >> 10;
-            const int wpt = (nwords + THREADS - 1) / THREADS;
-            int sc = 0;
-            for (int j = 0; j < wpt; j++) {
-                const int wd = tid * wpt + j;
-                sc += wd < nwords ? __popc(coarse[wd]) : 0;
-            }
-            int ngroups;
-            int r1 = block_exclusive_scan_1b<THREADS, int32_t>(sc, tmp_b, &ngroups);
-            for (int j = 0; j < wpt; j++) {
-                const int wd = tid * wpt + j;
-                if (wd < nwords) {
-                    cpre[wd] = (uint16_t)r1;
-                    r1 += __popc(coarse[wd]);
-                }
-            }
-            __syncthreads();
-            if (active) {
-                int fi[U];
+                for (int j = 0; j < U; j++) key[j] = (uint32_t)(b_ix[pos[j]] - wbase) + 1u;
+                // the first probes of all eight keys go out together; a key that meets another one walks on alone
 #pragma unroll
                 for (int j = 0; j < U; j++) {
-                    const int g = cc[j] >> 5;
-                    fi[j] = (int)cpre[g >> 5] + __popc(coarse[g >> 5] & ((1u << (g & 31)) - 1u));
+                    h[j] = (key[j] * 0x9E3779B1u) >> (32 - S2_TAB_LOG2);
+                    old[j] = atomicCAS(&tab[h[j]], 0u, key[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < U; j++) atomicOr(&fine[fi[j]], 1u << (cc[j] & 31));
+                for (int j = 0; j < U; j++) {
+                    uint32_t o = old[j], hh = h[j];
+                    while (o != 0u && o != key[j]) {   // ends: the set holds at most S2_CAP of its S2_TAB slots
+                        hh = (hh + 1u) & (uint32_t)(S2_TAB - 1);
+                        o = atomicCAS(&tab[hh], 0u, key[j]);
+                    }
+                    mycount += o == 0u;
+                }
             }
             __syncthreads();
-            // count and clear: thread t owns fine words [8t, 8t + 8) and its words of the group bitmap
-            {
-                const uint4 fa = ((const uint4*)fine)[2 * tid], fb = ((const uint4*)fine)[2 * tid + 1];
-                const int c = __popc(fa.x) + __popc(fa.y) + __popc(fa.z) + __popc(fa.w) + __popc(fb.x) + __popc(fb.y) +
-                              __popc(fb.z) + __popc(fb.w);
-                if (c) {
-                    ((uint4*)fine)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
-                    ((uint4*)fine)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
-                }
-                mycount += c;
-                for (int j = 0; j < wpt; j++) {
-                    const int wd = tid * wpt + j;
-                    if (wd < nwords) coarse[wd] = 0u;
-                }
-            }
-            // the next window's first writes to these arrays follow the barriers of its directory build
+            // clear the set: the next window's first insertions follow the two barriers of its directory build
+            static_assert(S2_TAB == 16 * THREADS, "four 16-byte stores per thread");
+#pragma unroll
+            for (int j = 0; j < 4; j++) ((uint4*)tab)[j * THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
         } else {
             // ---- plain bitmap of the window in `fine`, products through the directory cursor --------------------
             int2* dir = dirs[0];
