@@ -226,7 +226,7 @@ def main():
            ("slab_plan", capi.PH_SLAB_PLAN)]}
     ctx.profile(False)
     stamps = None
-    if os.environ.get("SPMM_WIN_STAMPS") in ("1", "2", "3"):
+    if os.environ.get("SPMM_WIN_STAMPS") in ("1", "2", "3", "4"):
         st = ctx.debug_stamps().astype(np.float64)
         names = ["directory", "sweep_own", "sweep_wait", "prefix", "value_own", "value_wait", "output_rest", "output_vals", "windows", "products"]
         stamps = {k: {n: (round(float(v)) if n in ("windows", "products") else round(float(v) / max(st[o:o + 8].sum(), 1), 3))

@@ -67,7 +67,7 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
 #endif
     if (const char* e = getenv("SPMM_DENSE_BOUNDS")) c->dense_bounds = atoi(e);
     if (const char* e = getenv("SPMM_DENSE_BOUNDS_MAX")) c->dense_bounds_max = atoll(e);
-    if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e);   // 1: every window kernel, 2: the 1024-thread cursor kernel only, 3: the 256-thread one only
+    if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e);   // 1: every window kernel, 2: the 1024-thread cursor kernel only, 3: the 256-thread one only, 4: the dense kernel only (1 mixes the kernels' sums in some slots)
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
     c->pinned_bytes = 4096;

@@ -3140,7 +3140,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                                    (int)bins.n_dense, A->indptr, A->indices, A->data, bins.winptr, bins.nbase, doff, (int)gr.i0, (int)gr.i1,
                                    dbound, dav);
             }
-            auto kd = ctx->win_stamps == 1 ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
+            auto kd = (ctx->win_stamps == 1 || ctx->win_stamps == 4) ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
                                            : (lb ? k_dense<1024, false, true> : k_dense<1024, false, false>);
             HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
             auto launch = [&](const int32_t* list_g, long long n_g, const int32_t* list_w, long long n_dense) {
