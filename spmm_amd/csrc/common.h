@@ -64,6 +64,11 @@ struct plan_cache {
     bool has_table = false;   // the window table of B was built (only products with window rows need it)
     bool has_slab = false;    // the slab order of B was built (likewise)
     bool slab = false;        // the plan is one without the window table
+    // B's 12-byte records as the last numeric call packed them: buffer, entries, digests of B's structure and values
+    bool b12_valid = false;
+    const void* b12_ptr = nullptr;
+    int b12_nnz = 0;
+    unsigned long long b12_dig_b = 0, b12_dig_v = 0;
     // the row lists of the last classification, reusable by a numeric call over the same rows of the same matrices
     bool lists_valid = false;
     int l_row_beg = 0, l_row_end = 0;

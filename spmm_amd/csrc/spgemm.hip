@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_
     }
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_DENSE_ENT = 14, CNT_N = 15 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_DENSE_ENT = 14, CNT_DIG_VAL = 15, CNT_N = 16 };
 
 // ---------------------------------------------------------------------------
 // P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
@@ -312,6 +312,32 @@ __global__ void __launch_bounds__(256) k_struct_digest(const int32_t* __restrict
         if (d) atomicAdd((unsigned long long*)&counters[CNT_UNSORTED], (unsigned long long)d);
     }
     if (bad) counters[CNT_BAD] = 1;
+}
+
+// Content digest of B's values: a numeric call packs B's 12-byte records only when the structure digest, this digest
+// or the record buffer differ from those of the call that packed them last (the row blocks of one product share B).
+__global__ void __launch_bounds__(256) k_val_digest(const double* __restrict__ v, int64_t n, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[4];
+    unsigned long long h = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    auto value = [&](int64_t i, double x) {
+        h += mix64((unsigned long long)__double_as_longlong(x) + ((unsigned long long)i + 0x3000000000ull) * 0x9e3779b97f4a7c15ull);
+    };
+    const int64_t n2 = ((uintptr_t)v & 15) == 0 ? n >> 1 : 0;
+#pragma unroll 4
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n2; q += stride) {
+        const double2 x = ((const double2*)v)[q];
+        value(2 * q, x.x);
+        value(2 * q + 1, x.y);
+    }
+    for (int64_t i = 2 * n2 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) value(i, v[i]);
+    h = wave_reduce_sum(h);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out, t);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2896,6 +2922,11 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         };
         if (!same) digest(A, CNT_DIG_A, 0);
         digest(B, CNT_DIG_B, 1);
+        if (mode == BINS_NUMERIC && !slab && B->nnz > 0) {
+            int64_t g = ((int64_t)B->nnz + 256 * 16 - 1) / (256 * 16);
+            if (g > 1024) g = 1024;
+            hipLaunchKernelGGL(k_val_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->data, (int64_t)B->nnz, dg + CNT_DIG_VAL);
+        }
     }
     bool hit = false;
     if (!fresh && pc.valid && pc.slab == slab && pc.a_nrow == A->nrow && pc.a_nnz == A->nnz && pc.b_nrow == B->nrow &&
@@ -3003,9 +3034,21 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     // numeric: B's entries as 12-byte records (the values are this call's)
     if (mode == BINS_NUMERIC && !slab && (out->n_w > 0 || out->n_g > 0) && B->nnz > 0) {
         CHK(ws(ctx, WS_B12, (size_t)B->nnz * 3 + 4, &out->b12));
-        int64_t g = ((int64_t)B->nnz + 255) / 256;
-        if (g > 256 * 16) g = 256 * 16;
-        hipLaunchKernelGGL(k_pack_b12, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->indices, B->data, (int64_t)B->nnz, out->b12);
+        // the records of the last packing serve when they were made from the same column ids and values (content
+        // digests, read back with the counters above) and still lie where they were written
+        const unsigned long long dig_v = (unsigned long long)h[CNT_DIG_VAL];
+        const bool packed = !ctx->arena_on && pc.b12_valid && pc.b12_ptr == (const void*)out->b12 && pc.b12_nnz == B->nnz &&
+                            pc.b12_dig_b == dig_b && pc.b12_dig_v == dig_v;
+        if (!packed) {
+            int64_t g = ((int64_t)B->nnz + 255) / 256;
+            if (g > 256 * 16) g = 256 * 16;
+            hipLaunchKernelGGL(k_pack_b12, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->indices, B->data, (int64_t)B->nnz, out->b12);
+            pc.b12_valid = !ctx->arena_on;
+            pc.b12_ptr = out->b12;
+            pc.b12_nnz = B->nnz;
+            pc.b12_dig_b = dig_b;
+            pc.b12_dig_v = dig_v;
+        }
     }
     phase_end(ctx, ph);
     // the slab order of B, likewise

@@ -377,6 +377,44 @@ def test_plan_of_another_matrix_is_not_reused_dev_refill(ctx):
         assert np.array_equal(c_ix[:m].cpu().numpy(), outs[k][1]) and np.array_equal(c_val[:m].cpu().numpy(), outs[k][2])
 
 
+def test_numeric_sees_values_changed_in_place(ctx):
+    """numeric, new values written into the same device array, numeric again (twice, and on two row ranges): the
+    second and third results carry the new values, i.e. B's packed records are not reused across a change of values,
+    and are reusable when nothing changed."""
+    import torch
+    n, mats, outs = _same_shape_pair()
+    dev = torch.device("cuda", 0)
+    ip, ix, d = mats[0]
+    t_ip, t_ix = torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev)
+    t_d = torch.from_numpy(d).to(dev)
+    v = capi.dev_view(n, n, int(ix.size), t_ip, t_ix, t_d)
+    c_ip = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ctx.spgemm_symbolic_dev(v, v, c_ip)
+    ctx.sync()
+    m = int(outs[0][0][-1])
+    c_ix = torch.empty(m, dtype=torch.int32, device=dev)
+    c_val = torch.empty(m, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(5)
+    d2 = rng.integers(1, 5, d.size).astype(np.float64)
+    o_ip = outs[0][0]
+    _, od2, _ = orc.spgemm_numeric(n, (ip, ix, d2), (ip, ix, d2), o_ip)
+    half = n // 2
+    for vals, want in ((d, outs[0][2]), (d2, od2), (d2, od2), (d, outs[0][2])):
+        ctx.sync()
+        t_d.copy_(torch.from_numpy(vals))
+        torch.cuda.synchronize()
+        c_val.zero_()
+        torch.cuda.synchronize()
+        # two row ranges of the same product: the second call finds the first call's records
+        ctx.spgemm_numeric_dev(v, v, c_ip, 0, half, c_ix, c_val)
+        ctx.sync()
+        k = int(o_ip[half])
+        assert np.array_equal(c_val[:k].cpu().numpy(), want[:k])
+        ctx.spgemm_numeric_dev(v, v, c_ip, half, n, c_ix, c_val)
+        ctx.sync()
+        assert np.array_equal(c_val[:m - k].cpu().numpy(), want[k:]) and np.array_equal(c_ix[:m - k].cpu().numpy(), outs[0][1][k:])
+
+
 def test_product_sorted_rows_with_many_empty_b_rows(ctx):
     """Rows of A with thousands of entries but at most 8192 products (most of the rows of B they name are
     empty): the expand step of the sorting kernels walks many chunks of entries that add nothing."""
