@@ -1360,7 +1360,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         for (int i = 0; i < 24; i++) st_lds[i] = 0;
         st_lds[15] = win_clock();
         win_t0 = st_lds[15];
-        st_lds[16] = win_t0 - kern_t0;   // set-up: clearing the arrays and the cumulative table sums
+        if (THREADS == 256) st_lds[16] = win_t0 - kern_t0;   // set-up: clearing the arrays and the cumulative table sums
     }
 #define WIN_ARRIVE(k) if (STAMP && lane == 0) st_arr[(k) * NW + wv] = win_clock();
 #define WIN_SKEW(k, slot)                                                        \
@@ -1431,7 +1431,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
             }
             // products per wave: register-resident windows give every wave a fixed slice of U*64
             // products (waves past the end skip the window and issue nothing); the two-sweep form
-            // spreads the products evenly, in multiples of 64
+            // spreads the products evenly, in multiples of 64.  (Even slices for the register-resident windows
+            // too, with the turns past a wave's slice skipped, measured 631 against 378 ms: the guards split the
+            // straight-line code, and the eight loads of a lane no longer go out together.)
             const int per = fast ? U * 64 : ((Tc + NW - 1) / NW + 63) & ~63;
             if (fast && len > 0) {
                 // mark where this entry's products start, and the slices that start inside it
@@ -1774,7 +1776,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 }
             WIN_STAMP(7)   // value store loop
             if (fast) {
-                // column ids were stored with the values' ranks
+                // column ids were stored with the values' ranks (taken from the bitmap and staged through LDS like
+                // the two-sweep windows' instead: 475 against 378 ms)
             } else if (staged) {
                 // column ids through LDS (the rank prefix is no longer needed) for coalesced stores
                 int32_t* stage = (int32_t*)pre;
