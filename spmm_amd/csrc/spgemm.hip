@@ -2913,7 +2913,9 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     long long* h = (long long*)ctx->pinned;
     const bool same = A->indptr == B->indptr && A->indices == B->indices && A->nrow == B->nrow && A->nnz == B->nnz && A->ncol == B->ncol;
     // content digests of the structure arrays (B's is A's when the two views are the same arrays), and with B's the
-    // test that its column ids are in range and ascending within each row
+    // test that its column ids are in range and ascending within each row; a numeric call also takes the digest of
+    // B's values, which tells it whether the 12-byte records of the last packing still stand
+    bool have_dig_v = false;
     {
         unsigned long long* dg = (unsigned long long*)counters;
         auto digest = [&](const spmm_csr* M, int slot, int check) {
@@ -2925,7 +2927,11 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         };
         if (!same) digest(A, CNT_DIG_A, 0);
         digest(B, CNT_DIG_B, 1);
-        if (mode == BINS_NUMERIC && !slab && B->nnz > 0) {
+        // (not when the last classification, over the same rows, found no row for the window kernels: should this
+        // call's matrices be others after all, it packs the records without asking)
+        have_dig_v = mode == BINS_NUMERIC && !slab && B->nnz > 0 &&
+                     !(pc.valid && pc.lists_valid && pc.l_row_beg == row_beg && pc.l_row_end == row_end && pc.l_n_w + pc.l_n_g == 0);
+        if (have_dig_v) {
             int64_t g = ((int64_t)B->nnz + 256 * 16 - 1) / (256 * 16);
             if (g > 1024) g = 1024;
             hipLaunchKernelGGL(k_val_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->data, (int64_t)B->nnz, dg + CNT_DIG_VAL);
@@ -3040,13 +3046,13 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
         // the records of the last packing serve when they were made from the same column ids and values (content
         // digests, read back with the counters above) and still lie where they were written
         const unsigned long long dig_v = (unsigned long long)h[CNT_DIG_VAL];
-        const bool packed = !ctx->arena_on && pc.b12_valid && pc.b12_ptr == (const void*)out->b12 && pc.b12_nnz == B->nnz &&
+        const bool packed = have_dig_v && !ctx->arena_on && pc.b12_valid && pc.b12_ptr == (const void*)out->b12 && pc.b12_nnz == B->nnz &&
                             pc.b12_dig_b == dig_b && pc.b12_dig_v == dig_v;
         if (!packed) {
             int64_t g = ((int64_t)B->nnz + 255) / 256;
             if (g > 256 * 16) g = 256 * 16;
             hipLaunchKernelGGL(k_pack_b12, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->indices, B->data, (int64_t)B->nnz, out->b12);
-            pc.b12_valid = !ctx->arena_on;
+            pc.b12_valid = have_dig_v && !ctx->arena_on;
             pc.b12_ptr = out->b12;
             pc.b12_nnz = B->nnz;
             pc.b12_dig_b = dig_b;
