@@ -146,6 +146,7 @@ int ws_get(spmm_ctx* c, int slot, size_t bytes, void** out) {
         if (c->slot[slot]) HIPCHK(hipFree(c->slot[slot]));
         c->slot[slot] = nullptr;
         c->slot_bytes[slot] = 0;
+        if (slot == WS_B12) c->plan.b12_valid = false;   // the packed records of B went with the old allocation
         size_t want = bytes + bytes / 8 + 256;
         want = (want + 255) & ~(size_t)255;
         HIPCHK(hipMalloc(&c->slot[slot], want));
