@@ -1291,13 +1291,22 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     const int gmax = ((WORDS * 32) >> shift) / gsz;
     // two-level windows of a single-chunk row: up to 32 times as wide (the search below looks at 4 x 64 granules)
     const int gmax2 = !TWO || !single_chunk ? gmax : ((WORDS * 1024) >> shift) / gsz < 256 ? ((WORDS * 1024) >> shift) / gsz : 256;
+    // single-chunk rows: the entry's table row, first bound and value, asked for before the table sums so that these
+    // two dependent round trips run beside them
+    const int32_t* T = winptr;
+    int t_lo = 0, t_hi = 0;
+    if (single_chunk && tid < lenA) {
+        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
+        t_lo = T[0];
+        if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
+    }
     if (NUMERIC && adaptive) {
         for (int j = tid; j <= nh; j += THREADS) cs[j] = 0u;
         __syncthreads();
-        // (entry, granule) pairs dealt to the waves 64 granules of one entry at a time, eight loads in flight per
+        // (entry, granule) pairs dealt to the waves 64 granules of one entry at a time, sixteen loads in flight per
         // lane: a loop over the entries with one load per turn is a chain of memory round trips, a tenth of the
         // kernel's time for rows of a few entries
-        constexpr int CSU = 8;
+        constexpr int CSU = 16;
         const int gw = (nh + 64) & ~63;   // granule slots per entry (0 .. nh, padded to whole waves)
         const int npairs = lenA * gw;
         for (int p0 = wv * 64; p0 < npairs; p0 += THREADS * CSU) {
@@ -1347,14 +1356,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         return j1 * gsz < nbase ? j1 * gsz : nbase;
     };
     int w1_cur = window_end(0), w1_next = 0;
-    const int32_t* T = winptr;
-    int t_lo = 0, t_hi = 0;
-    if (single_chunk && tid < lenA) {
-        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
-        t_lo = T[0];
-        t_hi = T[w1_cur];
-        if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
-    }
+    if (single_chunk && tid < lenA) t_hi = T[w1_cur];
     unsigned long long win_t0 = 0;
     if (STAMP && tid == 0) {
         for (int i = 0; i < 24; i++) st_lds[i] = 0;
