@@ -308,6 +308,36 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
     }
 }
 
+// Row starts of the stream as a bitmap: bit p is set iff some row starts at stream position p.  The persistent chain
+// finds the end of the deciding element's row as the next set bit after it (one load) instead of searching the row
+// pointers (three dependent rounds), and records where each block starts in the stream; the rows are looked up after
+// the chain, all at once (k_cut_rows).
+__global__ void k_row_start_bits(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip, uint32_t* __restrict__ bits) {
+    GRID_STRIDE(x, (int64_t)nrow + 1) {
+        const int p = r_ip[x];
+        if (p < nnz) atomicOr(&bits[p >> 5], 1u << (p & 31));
+    }
+}
+// bsize[b] = first row whose row pointer is at or beyond the start of block b (the row after the one that holds the
+// deciding element of block b - 1); cutpos[b] < 0: the closing entry, nrow
+__global__ void k_cut_rows(int32_t nb, int32_t nrow, const int32_t* __restrict__ r_ip, const int32_t* __restrict__ cutpos,
+                           int32_t* __restrict__ bsize) {
+    GRID_STRIDE(b, (int64_t)nb + 1) {
+        const int p = cutpos[b];
+        int r = nrow;
+        if (b == 0) r = 0;
+        else if (p >= 0) {
+            int lo = 0, hi = nrow + 1;   // first x in [0, nrow] with r_ip[x] >= p (r_ip[nrow] = nnz >= p)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (r_ip[mid] >= p) hi = mid; else lo = mid + 1;
+            }
+            r = lo < nrow ? lo : nrow;
+        }
+        bsize[b] = r;
+    }
+}
+
 // The same chain in ONE launch: BC_TILES workgroups stay resident and walk the steps together.  Per step every
 // workgroup counts its tile, publishes the count and arrives on a counter; the workgroup whose arrival is the last of
 // the step decides (as above) and publishes the new state and the step number; the others wait for that number.
@@ -334,9 +364,9 @@ __global__ void k_block_chain_pinit(bc_pstate* st, int32_t* __restrict__ bsize, 
     }
 }
 
-__global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
+__global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t nnz, const uint32_t* __restrict__ rs_bits,
                                                                        const int32_t* __restrict__ prev, int32_t threshold,
-                                                                       int32_t* __restrict__ bsize, int32_t cap, bc_pstate* st,
+                                                                       int32_t* __restrict__ cutpos, int32_t cap, bc_pstate* st,
                                                                        int32_t max_spins) {
     static_assert(BC_TILES == 64, "one lane per tile count");
     __shared__ int32_t tmp[BC_THREADS / 64 + 1];
@@ -391,7 +421,7 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t n
                 n_cnt = cnt + run;
                 n_pos = pos + BC_TILES * BC_TILE;
                 if (n_pos >= nnz) {                                      // end of the stream: the last block takes the rest
-                    if (nb >= cap) n_over = 1; else if (tid == 0) bsize[nb] = nrow;
+                    if (nb >= cap) n_over = 1; else if (tid == 0) cutpos[nb] = -1;
                     n_done = 1;
                 }
             } else {
@@ -410,27 +440,35 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t n
                     sh[7] = q0 + (__ffs(m) - 1);
                 }
                 __syncthreads();
-                int lo = 0, hi = nrow + 1;
-                const int v = sh[7];
-                while (hi - lo > 1) {                                    // 1024-way search over the row pointers
-                    const int stp = (hi - lo + BC_THREADS - 1) / BC_THREADS;
-                    const int idx = lo + tid * stp;
-                    const int cc = __syncthreads_count(idx < hi && r_ip[idx] <= v);
-                    const int nlo = lo + (cc - 1) * stp;
-                    hi = lo + cc * stp < hi ? lo + cc * stp : hi;
-                    lo = nlo;
+                // the next block starts at the first row start after the deciding element
+                if (tid < 64) {
+                    const int p0 = sh[7] + 1;
+                    int found = nnz;
+                    for (int w0 = p0 >> 5; (long long)w0 * 32 < (long long)nnz; w0 += 64) {
+                        const int wi = w0 + tid;
+                        uint32_t bits = (long long)wi * 32 < (long long)nnz ? rs_bits[wi] : 0u;
+                        if (wi == (p0 >> 5)) bits &= ~0u << (p0 & 31);
+                        const unsigned long long m = __ballot(bits != 0u);
+                        if (m) {
+                            const int f = __ffsll(m) - 1;
+                            const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)bits, f);
+                            found = (w0 + f) * 32 + (__ffs(bw) - 1);
+                            break;
+                        }
+                    }
+                    if (tid == 0) sh[6] = found < nnz ? found : nnz;
                 }
-                const int r = lo;
+                __syncthreads();
+                const int ns = sh[6];
                 if (nb + 1 >= cap) {
                     n_over = 1;
                 } else {
-                    if (tid == 0) bsize[nb] = r + 1;
+                    if (tid == 0) cutpos[nb] = ns;
                     n_nb = nb + 1;
-                    const int ns = r_ip[r + 1];
                     n_s0 = n_pos = ns;
                     n_cnt = 0;
                     if (ns >= nnz) {                                     // the stream ends with this cut
-                        if (nb + 2 > cap) n_over = 1; else if (tid == 0) bsize[nb + 1] = nrow;
+                        if (nb + 2 > cap) n_over = 1; else if (tid == 0) cutpos[nb + 1] = -1;
                         n_done = 1;
                     }
                 }
@@ -739,23 +777,36 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
         // the whole chain in one launch of BC_TILES resident workgroups; falls through to the stepwise form when a
         // workgroup waited too long for the others (a grid that is not co-resident)
         bc_pstate* ps;
+        uint32_t* rs_bits;
+        int32_t* cutpos;
+        const size_t nwords = ((size_t)nnz + 31) / 32 + 64;
         CHK(ws(ctx, WS_MISC3, sizeof(bc_pstate) / sizeof(int32_t) + 1, (int32_t**)&ps));
-        hipLaunchKernelGGL(k_block_chain_pinit, dim3(1), dim3(64), 0, ctx->stream, ps, bsize, cap);
-        hipLaunchKernelGGL(k_block_chain_persistent, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, prev, threshold,
-                           bsize, cap, ps, ctx->chain_max_spins);
+        CHK(ws(ctx, WS_MISC2, nwords, &rs_bits));
+        CHK(ws(ctx, WS_MISC4, (size_t)cap + 1, &cutpos));
+        HIPCHK(hipMemsetAsync(rs_bits, 0, nwords * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_row_start_bits, dim3(grid_for((int64_t)nrow + 1, 256)), dim3(256), 0, ctx->stream, nrow, nnz, r_ip, rs_bits);
+        hipLaunchKernelGGL(k_block_chain_pinit, dim3(1), dim3(64), 0, ctx->stream, ps, cutpos, cap);
+        hipLaunchKernelGGL(k_block_chain_persistent, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nnz, rs_bits, prev, threshold,
+                           cutpos, cap, ps, ctx->chain_max_spins);
         HIPCHK(hipMemcpyAsync(h, ps, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (!h[7]) {     // no timeout
-            phase_end(ctx, ph);
             if (h[5]) {
+                phase_end(ctx, ph);
                 spmm_set_error("gen_blocks: more than %d blocks; the block list is too small", cap - 1);
                 return SPMM_E_CAPACITY;
             }
             if (!h[4]) {
+                phase_end(ctx, ph);
                 spmm_set_error("gen_blocks: the block chain ended without finishing");
                 return SPMM_E_HIP;
             }
-            *bnum_host = h[3];
+            // the rows of the cuts, all at once
+            const int32_t nb = h[3];
+            hipLaunchKernelGGL(k_cut_rows, dim3(grid_for((int64_t)nb + 1, 256)), dim3(256), 0, ctx->stream, nb, nrow, r_ip, cutpos, bsize);
+            HIPCHK(hipGetLastError());
+            phase_end(ctx, ph);
+            *bnum_host = nb;
             return SPMM_OK;
         }
     }
