@@ -143,12 +143,14 @@ int spmm_csr_from_coo(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, co
 int spmm_csr_from_coo_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
                           const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
 
-/* The same CSR build for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Device pointers as in
- * spmm_csr_from_coo_dev; every scratch buffer of the kernels comes out of one static device array of 24 MiB that
- * each GPU the library runs on holds until the process ends, so no hipMalloc/hipFree is issued, whatever was or
- * was not called on ctx before.  At most 2^20 entries and 2^20 rows (SPMM_E_CAPACITY beyond, nothing is run).
- * All calls on one GPU share that array: calls that overlap in time on one GPU race. */
+/* The same CSR build for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  Device pointers as in spmm_csr_from_coo_dev; every scratch
+ * buffer of the kernels comes out of one static device array of 24 MiB that each GPU the library runs on holds until
+ * the process ends, so no hipMalloc/hipFree is issued, whatever was or was not called on ctx before.  At most 2^20
+ * entries and 2^20 rows (SPMM_E_CAPACITY beyond, nothing is run).  All calls on one GPU share that array: calls that
+ * overlap in time on one GPU race.  Like spmm_csr_from_coo_dev it clears its counters with hipMemsetAsync and
+ * synchronises the stream once (the range check of the ids is read back by the host), so it allocates nothing but
+ * CANNOT be recorded into a HIP graph. */
 int spmm_csr_from_coo_dev_noalloc(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* row,
                                   const int32_t* col, int32_t* indptr, int32_t* indices, double* data);
 

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libspmm_hip.so")
+# SPMM_LIB_PATH names another build of the same library (the diagnostic build of `make -C spmm_amd/csrc diag`)
+LIB_PATH = os.environ.get("SPMM_LIB_PATH") or os.path.join(_HERE, "csrc", "libspmm_hip.so")
 _LIB = None
 
 I32, I64, F64 = np.int32, np.int64, np.float64

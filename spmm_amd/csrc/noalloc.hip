@@ -1,7 +1,8 @@
-// CSR build for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
-// harnesses that forbid hipMalloc): the same kernels as spmm_csr_from_coo_dev, with every scratch buffer (sort
-// double buffers, digit histograms, row ends, scan sums, the range-check flag) carved out of one static device
-// array instead of the context's hipMalloc'ed slots.
+// CSR build for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc):
+// the same kernels as spmm_csr_from_coo_dev, with every scratch buffer (sort double buffers, digit histograms, row
+// ends, scan sums, the range-check flag) carved out of one static device array instead of the context's hipMalloc'ed
+// slots.  The call still synchronises the stream once (the host reads the range check back) and clears counters with
+// hipMemsetAsync, so it is allocation-free but not something a HIP graph capture can record.
 #include "common.h"
 
 // One copy per GPU the library runs on, held until the process ends.  Every call on a GPU shares that GPU's copy,

@@ -1,6 +1,8 @@
 """GPU: the allocation-free CSR build (spmm_csr_from_coo_dev_noalloc, static device scratch) through the C ABI against
-the existing entry point spmm_csr_from_coo_dev, bit for bit, on two calls in a row, the second with a smaller input;
-the context issues no hipMalloc for them; sizes beyond the static scratch are refused."""
+the existing entry point spmm_csr_from_coo_dev AND against the CPU oracle (the restatement of
+serial_newblock_clock.cpp:78-112), bit for bit, on calls in a row that shrink and grow again, up to the entry point's
+limit of 2^20 entries and 2^20 rows (the static array at its fullest); the context issues no hipMalloc for them; sizes
+beyond the static scratch are refused."""
 import numpy as np
 import pytest
 
@@ -23,6 +25,7 @@ def _build(ctx, entry, n, ncol, row, col, dev):
 
 def test_csr_build_without_allocation_matches_the_allocating_entry_point():
     import torch
+    from oracle import oracle as orc
     from spmm_amd import capi, synth
     dev = torch.device("cuda", 0)
     fresh = capi.Context(0)          # has never allocated a scratch slot
@@ -38,6 +41,9 @@ def test_csr_build_without_allocation_matches_the_allocating_entry_point():
         r2[:64] = 3
         cases.append((1000, 300, r2, c2))
         cases.append((5, 7, np.zeros(0, np.int32), np.zeros(0, np.int32)))
+        # the limit itself: 2^20 entries over 2^20 rows (every scratch request at its largest), after the small calls
+        big_n = 1 << 20
+        cases.append((big_n, big_n, rng.integers(0, big_n, big_n).astype(np.int32), rng.integers(0, big_n, big_n).astype(np.int32)))
         before = fresh.device_allocs()
         assert before == 0
         for n, ncol, row, col in cases:
@@ -46,6 +52,8 @@ def test_csr_build_without_allocation_matches_the_allocating_entry_point():
             for g, w in zip(got, want):
                 assert np.array_equal(g, w)
             assert np.all(got[2] == 1.0) and got[0][0] == 0 and got[0][-1] == row.size
+            o_ip, o_ix, o_d = orc.csr_from_coo(n, row, col)       # the checker: the CPU oracle
+            assert np.array_equal(got[0], o_ip) and np.array_equal(got[1], o_ix) and np.array_equal(got[2], o_d)
         assert fresh.device_allocs() == before             # nothing was allocated
         assert ref.device_allocs() > 0
         # a context that has allocated before behaves the same
