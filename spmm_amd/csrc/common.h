@@ -119,9 +119,13 @@ struct spmm_ctx {
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
     int chain_persistent = 1;      // the greedy block chain in one persistent launch (0: one launch per step)
-    int chain_max_spins = 1 << 22; // polls of a workgroup waiting for the others before it gives up
+    int chain_max_spins = 1 << 22; // polls of a workgroup waiting for the others before it gives up, and
+    long long chain_max_wait_ticks = 2000000;   // the same bound in ticks of the 100 MHz clock (20 ms; a step takes about 10 us)
+    bool chain_spins_forced = false;            // SPMM_CHAIN_MAX_SPINS was set: a give-up is then not remembered
     int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
     long long table_max_bytes = 96ll << 30;
+    long long table_max_mib = -1;   // SPMM_TABLE_MAX_MIB, when set
+    int esc_max = 4096;     // rows of at most this many products take the sorting kernels (512 .. 8192)
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse
@@ -195,6 +199,15 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// The lanes of a wave exchange data through LDS without a workgroup barrier: LDS executes a
+// wave's instructions in order, so only the compiler has to be told that memory written by one
+// lane is read by another (it would otherwise forward a lane's own stores to its loads).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Wave-level scans use data-parallel-primitive moves (row shifts inside 16 lanes, then two row

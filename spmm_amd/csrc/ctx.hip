@@ -1,5 +1,6 @@
 // Context, error reporting and scratch management of libspmm_hip.so.
 #include "common.h"
+#include <cerrno>
 #include <cstdlib>
 
 static thread_local char g_err[512] = "";
@@ -14,6 +15,85 @@ void spmm_set_error(const char* fmt, ...) {
 extern "C" const char* spmm_last_error(void) { return g_err; }
 
 extern "C" void spmm_free(void* p) { free(p); }
+
+
+// ---------------------------------------------------------------------------
+// Kernel-selection switches, read from the environment when a context is created (tests force every path of the
+// library with them; the defaults are the measured best).  A value that is not a number, or lies outside the range
+// its path was written for, fails the creation with SPMM_E_ARG instead of being clamped or wrapped silently.
+namespace {
+
+bool parse_ll(const char* text, long long* out) {
+    if (text == nullptr || *text == 0) return false;
+    char* end = nullptr;
+    errno = 0;
+    const long long v = strtoll(text, &end, 10);
+    if (errno != 0 || end == text || *end != 0) return false;
+    *out = v;
+    return true;
+}
+
+// *field = the variable's value when it is set; false (with the error text) when it is not an integer in [lo, hi]
+// or, for multiple_of > 1, not a multiple of that
+template <typename T>
+bool env_int(const char* name, long long lo, long long hi, T* field, long long multiple_of = 1) {
+    const char* e = getenv(name);
+    if (e == nullptr) return true;
+    long long v;
+    if (!parse_ll(e, &v) || v < lo || v > hi || v % multiple_of != 0) {
+        if (multiple_of > 1)
+            spmm_set_error("%s=%s: expected a multiple of %lld in [%lld, %lld]", name, e, multiple_of, lo, hi);
+        else
+            spmm_set_error("%s=%s: expected an integer in [%lld, %lld]", name, e, lo, hi);
+        return false;
+    }
+    *field = (T)v;
+    return true;
+}
+
+int read_switches(spmm_ctx* c) {
+    const long long big = 1ll << 62;
+    bool ok = true;
+    ok = ok && env_int("SPMM_DENSE_MIN", -1, big, &c->dense_min);               // products; 0 = no dense kernel, -1 = by the table windows
+    ok = ok && env_int("SPMM_LIGHT_MAX", -1, big, &c->light_max);               // products; 0 = no light rows, -1 = by the table windows
+    ok = ok && env_int("SPMM_ESC_MAX", 512, 8192, &c->esc_max);                 // products of a row of the sorting kernels
+    ok = ok && env_int("SPMM_SYM_CFG", 0, 1, &c->sym_cfg);
+    ok = ok && env_int("SPMM_ADAPTIVE", 0, 1, &c->adaptive);
+    ok = ok && env_int("SPMM_LIGHT_TWO", 0, 1, &c->light_two);
+    ok = ok && env_int("SPMM_LIGHT_SYM", 0, 1, &c->light_sym);
+    ok = ok && env_int("SPMM_WIN_DENSE_OVER", 0, 1, &c->win_dense_over);
+    ok = ok && env_int("SPMM_SPLIT_GIANT", 0, 1, &c->split_giant);
+    ok = ok && env_int("SPMM_GIANT_MAJOR", 0, 1, &c->giant_major);
+    ok = ok && env_int("SPMM_GIANT_TASKS", 2, 512, &c->giant_tasks);            // workgroups per shared row
+    ok = ok && env_int("SPMM_GIANT_CHUNK", 1, 512, &c->giant_chunk);            // consecutive table windows per turn
+    ok = ok && env_int("SPMM_GIANT_LEN", 1, 0x7fffffffll, &c->giant_len);       // entries of A
+    ok = ok && env_int("SPMM_MAJOR_CHUNK", 4, 512, &c->major_chunk, 4);         // whole turns of four table-bound loads
+    ok = ok && env_int("SPMM_DENSE_SPARSE", 0, 8192, &c->dense_sparse);         // entries of C; 0 = no sparse runs
+    ok = ok && env_int("SPMM_DENSE_BOUNDS", 0, 1, &c->dense_bounds);
+    ok = ok && env_int("SPMM_DENSE_BOUNDS_MAX", 0, 1ll << 46, &c->dense_bounds_max);   // bytes
+    ok = ok && env_int("SPMM_MAX_GRID_THREADS", 1024, (1ll << 32) - 1, &c->max_grid_threads);
+    ok = ok && env_int("SPMM_CHAIN_PERSISTENT", 0, 1, &c->chain_persistent);
+    ok = ok && env_int("SPMM_CHAIN_MAX_SPINS", 1, 1ll << 30, &c->chain_max_spins);
+    ok = ok && env_int("SPMM_SLAB", -1, 1, &c->slab_mode);
+    ok = ok && env_int("SPMM_TABLE_MAX_MIB", 0, 1ll << 30, &c->table_max_mib);  // window table of B beyond this: slab order
+    ok = ok && env_int("SPMM_SLAB_WMAX", 64, 15360, &c->slab_wmax, 64);
+    ok = ok && env_int("SPMM_SLAB_THREADS", 256, 512, &c->slab_threads, 256);
+    ok = ok && env_int("SPMM_SLAB_DENSE_COLS", 0, 15360, &c->slab_dense_cols);
+    ok = ok && env_int("SPMM_SLAB_SMAX", 1024, 1ll << 40, &c->slab_smax);
+#ifdef SPMM_DIAG
+    // diagnostic builds only (make -C spmm_amd/csrc diag): timing experiments whose results are wrong when nonzero, and
+    // the window kernels instantiated with in-kernel cycle stamps (1: every window kernel, 2: the 1024-thread cursor
+    // kernel only, 3: the 256-thread one only, 4: the dense kernel only)
+    ok = ok && env_int("SPMM_WIN_DBG", 0, 0x7fffffffll, &c->win_dbg);
+    ok = ok && env_int("SPMM_WIN_STAMPS", 0, 4, &c->win_stamps);
+#endif
+    if (!ok) return SPMM_E_ARG;
+    c->chain_spins_forced = getenv("SPMM_CHAIN_MAX_SPINS") != nullptr;
+    if (c->table_max_mib >= 0) c->table_max_bytes = c->table_max_mib << 20;
+    return SPMM_OK;
+}
+
+}  // namespace
 
 extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     ARGCHK(out != nullptr);
@@ -39,35 +119,10 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
         return SPMM_E_HIP;
     }
     c->own_stream = true;
-    if (const char* e = getenv("SPMM_DENSE_MIN")) c->dense_min = atoll(e);
-    if (const char* e = getenv("SPMM_SYM_CFG")) c->sym_cfg = atoi(e);
-    if (const char* e = getenv("SPMM_LIGHT_MAX")) c->light_max = atoll(e);
-    if (const char* e = getenv("SPMM_GIANT_TASKS")) c->giant_tasks = atoi(e) > 1 ? atoi(e) : 2;
-    if (const char* e = getenv("SPMM_GIANT_CHUNK")) c->giant_chunk = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("SPMM_GIANT_MAJOR")) c->giant_major = atoi(e);
-    if (const char* e = getenv("SPMM_MAX_GRID_THREADS")) { long long v = atoll(e); if (v >= 1024 && v < (1ll << 32)) c->max_grid_threads = v; }
-    if (const char* e = getenv("SPMM_MAJOR_CHUNK")) c->major_chunk = atoi(e) > 0 ? (atoi(e) + 3) & ~3 : 4;   // whole turns of table-bound loads
-    if (const char* e = getenv("SPMM_SPLIT_GIANT")) c->split_giant = atoi(e);
-    if (const char* e = getenv("SPMM_GIANT_LEN")) c->giant_len = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("SPMM_CHAIN_PERSISTENT")) c->chain_persistent = atoi(e);
-    if (const char* e = getenv("SPMM_CHAIN_MAX_SPINS")) c->chain_max_spins = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("SPMM_SLAB")) c->slab_mode = atoi(e);
-    if (const char* e = getenv("SPMM_TABLE_MAX_GIB")) c->table_max_bytes = (long long)(atof(e) * (double)(1ll << 30));
-    if (const char* e = getenv("SPMM_SLAB_WMAX")) { int v = atoi(e) & ~63; c->slab_wmax = v < 64 ? 64 : v > 15360 ? 15360 : v; }
-    if (const char* e = getenv("SPMM_SLAB_THREADS")) c->slab_threads = atoi(e) == 256 ? 256 : 512;
-    if (const char* e = getenv("SPMM_SLAB_DENSE_COLS")) c->slab_dense_cols = atoi(e) < 0 ? 0 : atoi(e);
-    if (const char* e = getenv("SPMM_SLAB_SMAX")) { long long v = atoll(e); c->slab_smax = v < 1024 ? 1024 : v; }
-    if (const char* e = getenv("SPMM_ADAPTIVE")) c->adaptive = atoi(e);
-    if (const char* e = getenv("SPMM_DENSE_SPARSE")) c->dense_sparse = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("SPMM_LIGHT_TWO")) c->light_two = atoi(e);
-    if (const char* e = getenv("SPMM_WIN_DENSE_OVER")) c->win_dense_over = atoi(e);
-    if (const char* e = getenv("SPMM_LIGHT_SYM")) c->light_sym = atoi(e);
-#ifdef SPMM_DIAG
-    if (const char* e = getenv("SPMM_WIN_DBG")) c->win_dbg = atoi(e);   // diagnostic builds only: results are wrong when nonzero
-#endif
-    if (const char* e = getenv("SPMM_DENSE_BOUNDS")) c->dense_bounds = atoi(e);
-    if (const char* e = getenv("SPMM_DENSE_BOUNDS_MAX")) c->dense_bounds_max = atoll(e);
-    if (const char* e = getenv("SPMM_WIN_STAMPS")) c->win_stamps = atoi(e);   // 1: every window kernel, 2: the 1024-thread cursor kernel only, 3: the 256-thread one only, 4: the dense kernel only (1 mixes the kernels' sums in some slots)
+    if (int rc = read_switches(c)) {
+        spmm_ctx_destroy(c);
+        return rc;
+    }
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
     c->pinned_bytes = 4096;

@@ -367,7 +367,7 @@ __global__ void k_block_chain_pinit(bc_pstate* st, int32_t* __restrict__ bsize, 
 __global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t nnz, const uint32_t* __restrict__ rs_bits,
                                                                        const int32_t* __restrict__ prev, int32_t threshold,
                                                                        int32_t* __restrict__ cutpos, int32_t cap, bc_pstate* st,
-                                                                       int32_t max_spins) {
+                                                                       int32_t max_spins, long long max_wait_ticks) {
     static_assert(BC_TILES == 64, "one lane per tile count");
     __shared__ int32_t tmp[BC_THREADS / 64 + 1];
     __shared__ int32_t sh[8];          // s0, pos, cnt, nb, stop, last, hit, cut
@@ -482,9 +482,11 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t n
         }
         // ---- everybody: the state after this step ----------------------------------------------------------------------------
         if (tid == 0) {
+            // a wait ends after max_spins polls or max_wait_ticks of the constant 100 MHz clock, whichever comes first
             int spins = 0, stop = 0;
+            const long long t0 = (long long)wall_clock64();
             while (ld_sc1(&st->gen) < step + 1) {
-                if (ld_sc1(&st->timeout) || ++spins > max_spins) {
+                if (ld_sc1(&st->timeout) || ++spins > max_spins || ((spins & 31) == 0 && (long long)wall_clock64() - t0 > max_wait_ticks)) {
                     st_sc1(&st->timeout, 1);
                     stop = 1;
                     break;
@@ -787,7 +789,7 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
         hipLaunchKernelGGL(k_row_start_bits, dim3(grid_for((int64_t)nrow + 1, 256)), dim3(256), 0, ctx->stream, nrow, nnz, r_ip, rs_bits);
         hipLaunchKernelGGL(k_block_chain_pinit, dim3(1), dim3(64), 0, ctx->stream, ps, cutpos, cap);
         hipLaunchKernelGGL(k_block_chain_persistent, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nnz, rs_bits, prev, threshold,
-                           cutpos, cap, ps, ctx->chain_max_spins);
+                           cutpos, cap, ps, ctx->chain_max_spins, ctx->chain_max_wait_ticks);
         HIPCHK(hipMemcpyAsync(h, ps, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (!h[7]) {     // no timeout
@@ -809,6 +811,10 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
             *bnum_host = nb;
             return SPMM_OK;
         }
+        // A wait ran out: the 64 workgroups were not resident together (a GPU shared with other work).  Later calls of
+        // this context go straight to the stepwise form instead of waiting again (unless the poll bound was set from
+        // the environment, which is how the tests reach this path on every call).
+        if (!ctx->chain_spins_forced) ctx->chain_persistent = 0;
     }
     hipLaunchKernelGGL(k_block_chain_init, dim3(1), dim3(64), 0, ctx->stream, st, bsize, cap);
     // one launch per step of the chain; the number of steps (blocks + windows without a cut) is only

@@ -48,15 +48,22 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WTILE;
     uint32_t key[RS_STEPS];
     int32_t rank[RS_STEPS];
-    volatile int32_t* mycnt = wcnt[w];
+    // all keys of the lane first, so that the sixteen loads are in flight together
+#pragma unroll
+    for (int s = 0; s < RS_STEPS; s++) {
+        const int64_t i = wbase + s * 64 + lane;
+        key[s] = i < n ? keys_in[i] : 0u;
+    }
+    // The wave's digit counters are read and written by different lanes from step to step.  LDS executes a wave's
+    // instructions in order, so a wavefront-scope fence (no workgroup barrier) is all that is needed; the pointer stays a
+    // plain LDS pointer (a volatile one makes every access a flat instruction, which waits for all outstanding global
+    // loads as well).
+    int32_t* mycnt = wcnt[w];
     const unsigned long long lt = lanemask_lt();
 #pragma unroll
     for (int s = 0; s < RS_STEPS; s++) {
-        int64_t i = wbase + s * 64 + lane;
-        bool valid = i < n;
-        uint32_t k = valid ? keys_in[i] : 0u;
-        key[s] = k;
-        uint32_t d = (k >> shift) & 255u;
+        const bool valid = wbase + s * 64 + lane < n;
+        const uint32_t d = (key[s] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -64,12 +71,12 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
             m &= ((d >> b) & 1u) ? bb : ~bb;
         }
         // lanes of m hold the same digit (invalid lanes are excluded from every m of valid lanes)
-        int before = valid ? mycnt[d] : 0;
-        int r = __popcll(m & lt);
+        const int before = valid ? mycnt[d] : 0;
+        const int r = __popcll(m & lt);
         rank[s] = before + r;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();   // every lane has read its counter
         if (valid && r == 0) mycnt[d] = before + __popcll(m);
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();   // the new counts are there for the next step
     }
     __syncthreads();
     __shared__ int32_t tbase[256];            // first position of a digit inside the tile, in digit order

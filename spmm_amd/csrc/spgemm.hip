@@ -40,31 +40,30 @@ constexpr int ESC_S_CAP = 512;
 #define ESC_T_LANES 8      // this many lanes each (8 x 64 measured best on web-sized graphs; 16 x 64: +5 %, 16 x 128: +10 %)
 #endif
 constexpr int ESC_L_CAP = 4096;
-constexpr int ESC_MAX_DEFAULT = 4096;   // measured at R-MAT-22: 8192 -> 4096 saves 17 ms of numeric and costs 9 ms of symbolic; lower limits cost more symbolic time than they save
+constexpr int ESC_MAX_DEFAULT = 4096;   // spmm_ctx::esc_max (SPMM_ESC_MAX): measured at R-MAT-22: 8192 -> 4096 saves 17 ms of numeric and costs 9 ms of symbolic; lower limits cost more symbolic time than they save
 constexpr int ESC_R_CAP = 8192;         // radix expand-sort-compress: rows with up to this many products and 65535 entries
-// Rows above this many products take the window kernels (at most ESC_R_CAP, at least ESC_S_CAP; SPMM_ESC_MAX sets it).
-static int esc_max_products() {
-    const char* e = getenv("SPMM_ESC_MAX");
-    const int x = e ? atoi(e) : ESC_MAX_DEFAULT;
-    return x < ESC_S_CAP ? ESC_S_CAP : x > ESC_R_CAP ? ESC_R_CAP : x;
-}
 constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14 .. 2^17 columns
 constexpr int WIN_SHIFT_MAX = 17;
 constexpr int KEY_PAD = 0x7fffffff;
-
-// The lanes of a wave exchange data through LDS without a workgroup barrier: LDS executes a
-// wave's instructions in order, so only the compiler has to be told that memory written by one
-// lane is read by another (it would otherwise forward a lane's own stores to its loads).
-__device__ __forceinline__ void wave_sync_lds() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // B as 12-byte records {column id, value}: a short piece of a row of B (most pieces a window kernel reads hold a few
 // products) then lies in one cache line instead of one line of column ids and one of values.  Packed by every
 // numeric call (k_pack_b12) from the caller's arrays.
 struct colval { int col; double val; };
+// Pointers to global memory that say so in their type.  Inside a kernel the compiler infers the address space of the
+// kernel's pointer arguments; inside a function that is NOT inlined an ordinary pointer argument is a generic one, and
+// every access through it is a flat instruction, which counts as both a vector-memory and an LDS operation, so that
+// waits on either kind drain both.  Such functions convert their pointers on entry.
+#define SPMM_GLOBAL __attribute__((address_space(1)))
+typedef const SPMM_GLOBAL uint32_t* gptr_cu32;
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ colval ld_b12(gptr_cu32 b12, int pos) {
+    const u32x3 r = *reinterpret_cast<const SPMM_GLOBAL u32x3*>(b12 + 3ull * (unsigned)pos);
+    colval cv;
+    cv.col = (int)r.x;
+    cv.val = __hiloint2double((int)r.z, (int)r.y);
+    return cv;
+}
 __device__ __forceinline__ colval ld_b12(const uint32_t* __restrict__ b12, int pos) {
     const uint3 r = *reinterpret_cast<const uint3*>(b12 + 3ull * (unsigned)pos);
     colval cv;
@@ -85,12 +84,12 @@ __global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_
     }
 }
 
-enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_DENSE_ENT = 14, CNT_DIG_VAL = 15, CNT_N = 16 };
+enum { CNT_ESC_S = 0, CNT_ESC_L = 1, CNT_WIN = 2, CNT_PRODUCTS = 3, CNT_BAD = 4, CNT_UNSORTED = 5, CNT_DENSE = 6, CNT_ESC_M = 7, CNT_GIANT_ALL = 8, CNT_GIANT = 9, CNT_LIGHT = 10, CNT_ESC_T = 11, CNT_DIG_A = 12, CNT_DIG_B = 13, CNT_DENSE_ENT = 14, CNT_DIG_VAL = 15, CNT_BAD_PTR = 16, CNT_N = 17 };
 
 // ---------------------------------------------------------------------------
 // P_i per row: sixteen lanes per row (the average row has sixteen entries), rows of more than 4096 entries
 // by a whole wave afterwards.
-__global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrowB, const int32_t* __restrict__ a_ip,
+__global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrowB, int32_t nnzA, const int32_t* __restrict__ a_ip,
                                                       const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ip,
                                                       int64_t* __restrict__ prod, long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63, sub = lane & 15;
@@ -100,7 +99,11 @@ __global__ void __launch_bounds__(256) k_row_products(int32_t nrow, int32_t nrow
     for (int64_t rowbase = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane) >> 4; rowbase < nrow; rowbase += ng) {
         const int64_t row = rowbase + (lane >> 4);
         const bool have = row < nrow;
-        const int a0 = have ? a_ip[row] : 0, a1 = have ? a_ip[row + 1] : 0;
+        // (row pointers are clamped to the entry array: this kernel runs before the host has seen the verdict of the
+        // structure check on them, and must not read outside the arrays whatever they hold)
+        int a0 = have ? a_ip[row] : 0, a1 = have ? a_ip[row + 1] : 0;
+        a0 = a0 < 0 ? 0 : a0 > nnzA ? nnzA : a0;
+        a1 = a1 < a0 ? a0 : a1 > nnzA ? nnzA : a1;
         const bool longrow = a1 - a0 > 4096;
         long long s = 0;
         if (!longrow)
@@ -276,11 +279,16 @@ __global__ void __launch_bounds__(256) k_struct_digest(const int32_t* __restrict
     long long descents = 0;
     bool bad = false;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    bool bad_ptr = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= nrow; i += stride) {
         const int s = ip[i];
         h += mix64((unsigned long long)(uint32_t)s + ((unsigned long long)i + 0x1000000000ull) * 0x9e3779b97f4a7c15ull);
+        // the row pointers must lie in [0, n_ix] and never descend (a view of a row range starts above 0): every kernel
+        // downstream indexes the entry arrays through them without another look
+        bad_ptr |= s < 0 || s > n_ix || (i < nrow && ip[i + 1] < s);
         if (check && i < nrow && s > 0 && s < n_ix && s < ip[i + 1] && ix[s] < ix[s - 1]) descents--;
     }
+    if (bad_ptr) counters[CNT_BAD_PTR] = 1;
     auto column = [&](int64_t i, int c, int before) {
         h += mix64((unsigned long long)(uint32_t)c + ((unsigned long long)i + 0x2000000000ull) * 0x9e3779b97f4a7c15ull);
         if (check) {
@@ -938,8 +946,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // only read when WITH_VAL.  between() is called exactly once, after the loads of the first batch
 // have been issued (or at the end when there is no batch): work of the caller that consumes
 // earlier loads goes there, so that those and the batch's loads are in flight together.
-template <bool WITH_VAL, typename F, typename G>
-__device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix, const uint32_t* __restrict__ b12, int s,
+template <bool WITH_VAL, typename PIX, typename P12, typename F, typename G>
+__device__ __forceinline__ void wave_flat_sweep(PIX b_ix, P12 b12, int s,
                                                 int rem, double a, int lane, uint8_t* wmap, F&& act, G&& between) {
     uint32_t* wmap4 = (uint32_t*)wmap;
     rem = rem > 0 ? rem : 0;
@@ -996,7 +1004,7 @@ __device__ __forceinline__ void wave_flat_sweep(const int32_t* __restrict__ b_ix
             const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last product
             sq[j] = (int)wmap[qc - b0] - 1;
             const int pos = __shfl(so, sq[j], 64) + qc;
-            if (WITH_VAL) {
+            if constexpr (WITH_VAL) {
                 const colval cv = ld_b12(b12, pos);
                 bq[j] = cv.val;
                 cq[j] = cv.col;
@@ -1029,6 +1037,8 @@ __device__ __forceinline__ void store_b128(double* p, double a, double b) {
     const v2f64 v = {a, b};
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void store_b128(SPMM_GLOBAL int32_t* p, int a, int b, int c, int d) { store_b128((int32_t*)p, a, b, c, d); }
+__device__ __forceinline__ void store_b128(SPMM_GLOBAL double* p, double a, double b) { store_b128((double*)p, a, b); }
 
 // ---------------------------------------------------------------------------
 // One table window of a cursor row that holds more products than a register-resident window, with dense accumulators
@@ -1042,8 +1052,8 @@ __device__ __forceinline__ void store_b128(double* p, double a, double b) {
 // inlined: the cursor kernel runs at the register limit of 1024-thread workgroups, and this code's registers would
 // push its common path into spills (measured: 395 -> 458 ms).
 template <int THREADS, int WORDS, int VALS, int PRE_BYTES>
-__device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, const uint32_t* __restrict__ b12, int wbase,
-                                                                   int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+__device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, const uint32_t* __restrict__ b12_arg, int wbase,
+                                                                   int32_t* __restrict__ c_ix_arg, double* __restrict__ c_val_arg) {
     // the cursor kernel's numeric LDS layout: bitmap, rank prefixes, compact sums, A's values, two directory buffers,
     // three scan buffers
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1055,6 +1065,9 @@ __device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, con
     static_assert(dirav_off >= (uint32_t)DENSE_COLS * 8u, "a sum per column of a table window");
     static_assert((size_t)(THREADS + 1) * 8 >= DENSE_COLS / 8 + NW * 256, "flag bits and wave maps fit one directory buffer");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const gptr_cu32 b12 = (gptr_cu32)b12_arg;
+    SPMM_GLOBAL int32_t* const c_ix = (SPMM_GLOBAL int32_t*)c_ix_arg;
+    SPMM_GLOBAL double* const c_val = (SPMM_GLOBAL double*)c_val_arg;
     double* acc = (double*)smem;
     const int2* dir = (const int2*)(smem + dirbuf_off) + flip * (THREADS + 1);
     const double* dir_av = (const double*)(smem + dirav_off);
@@ -1102,8 +1115,8 @@ __device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, con
         // a thread's entries are consecutive in C: column ids four per store, values two per store, single stores
         // for what is left
         const int cnt = __popc(m16);
-        int32_t* const pi = c_ix + r;
-        double* const pv = c_val + r;
+        SPMM_GLOBAL int32_t* const pi = c_ix + r;
+        SPMM_GLOBAL double* const pv = c_val + r;
         unsigned mm = m16;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1264,7 +1277,10 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         for (int i = tid; i < VALS; i += THREADS) vals[i] = 0.0;
     int mycount = 0;
     // stamp accumulators live in LDS so that the diagnostic build keeps the register allocation
-    unsigned long long* st_lds = (unsigned long long*)(((uintptr_t)(tmp + 3 * (NW + 1)) + 7) & ~(uintptr_t)7);
+    // (aligned by OFFSETS from the start of the dynamic LDS: a pointer that went through an integer loses its LDS
+    // address space, and every access through it becomes a flat instruction that the compiler orders behind ALL
+    // outstanding global loads and stores)
+    unsigned long long* st_lds = (unsigned long long*)(smem + ((((unsigned char*)(tmp + 3 * (NW + 1)) - smem) + 7) & ~(ptrdiff_t)7));
     unsigned long long* st_arr = st_lds + 24;   // 5 x NW arrival times; st_lds[16..23]: register-resident windows by products (count, cycles)
     // Adaptive windows (numeric): R-MAT-like rows put a quarter of their products into the first
     // few table windows, so equal-width windows sized by the row average overflow the registers
@@ -1278,7 +1294,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
     // and a column's rank is the rank prefix of its fine word plus the bits below it.  Rows of few products in a
     // wide matrix get windows filled with products instead of windows cut by the bitmap's width.
     static_assert(!TWO || (NUMERIC && PRE16 && U == 8), "two-level windows: 16-bit ranks, eight products per lane");
-    uint32_t* fine = (uint32_t*)(((uintptr_t)(wave_ent + NW) + 15) & ~(uintptr_t)15);   // TWO: U*THREADS words
+    uint32_t* fine = (uint32_t*)(smem + ((((unsigned char*)(wave_ent + NW) - smem) + 15) & ~(ptrdiff_t)15));   // TWO: U*THREADS words
     uint16_t* fpre = (uint16_t*)(fine + U * THREADS);                                    // TWO: rank prefix per fine word
     if (TWO)
         for (int i = tid; i < U * THREADS; i += THREADS) fine[i] = 0u;   // ordered before the first use by the barriers of the directory build
@@ -1422,6 +1438,16 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                     if (NUMERIC) dir_av[tid] = a_val[a0 + e];
                 }
             }
+            // (diagnostic builds: dbg bits 12..16 run one section of a register-resident window a second time, with the same
+            // results, so that the section's cost shows as the difference of two timings)
+            if ((dbg & 0x1000) && single_chunk) {
+                int tc2;
+                const int off2 = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_dir, &tc2);
+                dir[tid] = make_int2(off2, s);
+                if (NUMERIC && tc2 <= U * THREADS && len > 0) emap[off2] = (uint16_t)(tid + 1);
+                __syncthreads();
+                __syncthreads();
+            }
             const int off = single_chunk ? block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_dir, &Tc)
                                          : block_exclusive_scan<THREADS, int32_t>(len, tmp, &Tc);
             dir[tid] = make_int2(off, s);
@@ -1470,6 +1496,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 // Straight-line code: lanes past the end of the slice repeat its last product with
                 // an empty bit mask and a zero addend.
                 active = true;
+                for (int rep = (dbg & 0x2000) ? 0 : 1; rep < 2; rep++)
                 {
                     // running maximum of the marks over the slice = entry (+1) of every product:
                     // each lane scans U consecutive marks, the wave combines, the result goes back
@@ -1492,6 +1519,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
+                for (int rep = (dbg & 0x4000) ? 0 : 1; rep < 2; rep++) {
                 int pos[U];
 #pragma unroll
                 for (int j = 0; j < U; j++) {
@@ -1515,6 +1543,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                     const int bit = TWO ? (cc[j] - wbase) >> 5 : cc[j] - wbase;
                     atomicOr(&bits[bit >> 5], valid ? 1u << (bit & 31) : 0u);
                     pv[j] = valid ? pv[j] * bv[j] : 0.0;
+                }
                 }
             } else {
                 WinCursor<THREADS> cur;
@@ -1574,6 +1603,9 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         const bool fullw = NUMERIC && WPT % 4 == 0 && wpt == WPT;
         int s = 0;
         uint32_t myw[WPT];
+        int cntw = 0, ex = 0;
+        for (int rep = (dbg & 0x8000) ? 0 : 1; rep < 2; rep++) {
+        s = 0;
         if (fullw) {
 #pragma unroll
             for (int j = 0; j < WPT / 4; j++) {
@@ -1586,8 +1618,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         }
 #pragma unroll
         for (int j = 0; j < WPT; j++) s += __popc(myw[j]);
-        int cntw;
-        const int ex = block_exclusive_scan_1b<THREADS, int32_t>(s, tmp_pre, &cntw);
+        ex = block_exclusive_scan_1b<THREADS, int32_t>(s, tmp_pre, &cntw);
         if (!(dbg & 32)) {
             if (fullw && PRE16) {
                 if constexpr (PRE16 && WPT % 8 == 0) {
@@ -1619,6 +1650,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                     if (j < wpt && tid * wpt + j < nwords) { pre[tid * wpt + j] = (pre_t)r; r += __popc(myw[j]); }
             }
         }
+        if (rep == 0) __syncthreads();   // (diagnostic repeat: the scan buffer is reused)
+        }
         const bool staged = cntw <= VALS && (size_t)cntw * 4 <= (size_t)WORDS * sizeof(pre_t);   // column staging reuses the rank-prefix array
         WIN_STAMP(3)   // rank prefix
         if constexpr (TWO) {
@@ -1627,10 +1660,19 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 __syncthreads();   // group ranks complete
                 int fi[U];
                 if (active) {
+                    // (all reads of the U look-ups before the first use, here and below: see the plain windows)
+                    uint32_t pw[U], bw[U];
 #pragma unroll
                     for (int j = 0; j < U; j++) {
                         const int g = (cc[j] - wbase) >> 5;
-                        fi[j] = (int)pre[g >> 5] + __popc(bits[g >> 5] & ((1u << (g & 31)) - 1u));
+                        pw[j] = (uint32_t)pre[g >> 5];
+                        bw[j] = bits[g >> 5];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int g = (cc[j] - wbase) >> 5;
+                        fi[j] = (int)pw[j] + __popc(bw[j] & ((1u << (g & 31)) - 1u));
                     }
                     // lanes past the end of the slice repeat its last product: the same bit again
 #pragma unroll
@@ -1655,9 +1697,16 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 __syncthreads();   // column ranks complete
                 WIN_STAMP(3)
                 if (active) {
+                    uint32_t pw[U], bw[U];
 #pragma unroll
                     for (int j = 0; j < U; j++) {
-                        const int rk = (int)fpre[fi[j]] + __popc(fine[fi[j]] & ((1u << (cc[j] & 31)) - 1u));
+                        pw[j] = (uint32_t)fpre[fi[j]];
+                        bw[j] = fine[fi[j]];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int rk = (int)pw[j] + __popc(bw[j] & ((1u << (cc[j] & 31)) - 1u));
                         c_ix[out + rk] = cc[j];
                         cc[j] = rk;
                     }
@@ -1689,15 +1738,44 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 WIN_ARRIVE(1)
                 __syncthreads();   // rank prefix complete
                 WIN_SKEW(1, 11)
+                if (active && (dbg & 0x10000)) {   // diagnostic repeat: the same look-ups and stores, zero addends
+                    uint32_t pw[U], bw[U];
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int cj = cc[j] - wbase;
+                        pw[j] = (uint32_t)pre[cj >> 5];
+                        bw[j] = bits[cj >> 5];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    int rk[U];
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int cj = cc[j] - wbase;
+                        rk[j] = (int)pw[j] + __popc(bw[j] & ((1u << (cj & 31)) - 1u));
+                        c_ix[out + rk[j]] = cc[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; j++) atomicAdd(&vals[rk[j]], 0.0);
+                }
                 if (active) {
                     // All rank look-ups first: LDS reads cannot move across the atomics, so one
                     // loop would pay a full LDS round trip per product.  The column id goes
                     // straight to its rank in C (every product of a column stores the same
                     // value), which spares the bit-by-bit walk over the bitmap.
+                    // (the reads of all U look-ups are issued before the first is used: left to itself the compiler
+                    // waits for every read before it issues the next, a chain of U LDS round trips)
+                    uint32_t pw[U], bw[U];
 #pragma unroll
                     for (int j = 0; j < U; j++) {
                         const int cj = cc[j] - wbase;
-                        const int rk = (int)pre[cj >> 5] + __popc(bits[cj >> 5] & ((1u << (cj & 31)) - 1u));
+                        pw[j] = (uint32_t)pre[cj >> 5];
+                        bw[j] = bits[cj >> 5];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int cj = cc[j] - wbase;
+                        const int rk = (int)pw[j] + __popc(bw[j] & ((1u << (cj & 31)) - 1u));
                         c_ix[out + rk] = cc[j];
                         cc[j] = rk;
                     }
@@ -1771,6 +1849,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
             WIN_SKEW(3, 13)
             WIN_STAMP(5)   // wait for the other waves
             // ---- write out ranks [r0, r0+nsub) ------------------------------------
+            if (dbg & 0x20000)   // diagnostic repeat: the stores without the clearing
+                for (int r = tid; r < nsub; r += THREADS) c_val[out + r0 + r] = vals[r];
             if (!(dbg & 2))
                 for (int r = tid; r < nsub; r += THREADS) {
                     c_val[out + r0 + r] = vals[r];
@@ -2955,7 +3035,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     if (!hit && nrow > 0) {
         int64_t nb = ((int64_t)nrow + 15) / 16;
         if (nb > 256 * 64) nb = 256 * 64;
-        hipLaunchKernelGGL(k_row_products, dim3((unsigned)nb), dim3(256), 0, ctx->stream, nrow, B->nrow, A->indptr,
+        hipLaunchKernelGGL(k_row_products, dim3((unsigned)nb), dim3(256), 0, ctx->stream, nrow, B->nrow, A->nnz, A->indptr,
                            A->indices, B->indptr, out->prod, counters);
     }
     int32_t nr = row_end - row_beg;
@@ -2982,11 +3062,15 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     if (!reuse) {
         if (nr > 0)
             hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
-                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, esc_max_products(), giant_mode,
+                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, ctx->esc_max, giant_mode,
                                major ? 0 : ctx->giant_len, out->gslot, list_g0, (slab && mode != BINS_PRODUCTS) ? 1 : 0, out->slot_row, key_g0, counters);
         HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (same) h[CNT_DIG_A] = h[CNT_DIG_B];
+        if (h[CNT_BAD_PTR]) {
+            spmm_set_error("spgemm: row pointers of A or B descend or point outside [0, nnz]");
+            return SPMM_E_ARG;
+        }
         if (h[CNT_BAD]) {
             spmm_set_error("spgemm: a column id of A is outside [0, B.nrow) or one of B outside [0, B.ncol)");
             return SPMM_E_ARG;
@@ -3104,8 +3188,12 @@ int launch_win(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins& 
     static_assert(lds <= 160 * 1024, "LDS budget of one CU");
     unsigned long long* stamps;
     CHK(ws(ctx, WS_STAMPS, 32, &stamps));
+#ifdef SPMM_DIAG   // the stamped instantiations exist in diagnostic builds only
     auto kern = (ctx->win_stamps == 1 || (ctx->win_stamps == 2 && THREADS == 1024) || (ctx->win_stamps == 3 && THREADS == 256)) ? k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, true, TWO>
                                 : k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false, TWO>;
+#else
+    auto kern = k_win<THREADS, WORDS, VALS, U, UG, NUMERIC, false, TWO>;
+#endif
     HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for_row_slices(ctx, bins.n_w, THREADS, 1, [&](long long off, long long cnt) {
         hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(THREADS), lds, ctx->stream, bins.list_w + off, A->indptr,
@@ -3194,8 +3282,12 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                                    (int)bins.n_dense, A->indptr, A->indices, A->data, bins.winptr, bins.nbase, doff, (int)gr.i0, (int)gr.i1,
                                    dbound, dav);
             }
+#ifdef SPMM_DIAG
             auto kd = (ctx->win_stamps == 1 || ctx->win_stamps == 4) ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
                                            : (lb ? k_dense<1024, false, true> : k_dense<1024, false, false>);
+#else
+            auto kd = lb ? k_dense<1024, false, true> : k_dense<1024, false, false>;
+#endif
             HIPCHK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl));
             auto launch = [&](const int32_t* list_g, long long n_g, const int32_t* list_w, long long n_dense) {
                 const int n_shared = (int)(n_g * gtasks);
@@ -3352,9 +3444,18 @@ extern "C" int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* lig
     return SPMM_OK;
 }
 
+// The limits a context created now would use (it takes no context so that the host-side partitioning code can ask
+// without a GPU): SPMM_ESC_MAX when it holds an integer in [ESC_S_CAP, ESC_R_CAP], which is also the only kind of
+// value spmm_ctx_create accepts, else the default.
 extern "C" void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large) {
+    int lim = ESC_MAX_DEFAULT;
+    if (const char* e = getenv("SPMM_ESC_MAX")) {
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && *end == 0 && v >= ESC_S_CAP && v <= ESC_R_CAP) lim = (int)v;
+    }
     if (esc_small) *esc_small = ESC_S_CAP;
-    if (esc_large) *esc_large = esc_max_products();
+    if (esc_large) *esc_large = lim;
 }
 
 extern "C" int spmm_row_products_dev(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int64_t* prod, int64_t* total) {

@@ -25,7 +25,10 @@ pytestmark = pytest.mark.gpu
 # instead of dense accumulators for a table window that overfills a register-resident window; the sorting kernels for rows of up to 8192 products (the
 # default is 4096) and of up to 512 only; no window table of
 # B at all (every window row through the launches over B's slab order), with wide windows and dense accumulators,
-# and with narrow windows, the bitmap-rank accumulators and 256-thread workgroups.
+# and with narrow windows, the bitmap-rank accumulators and 256-thread workgroups; rows of very many entries NOT shared
+# between workgroups; such rows shared by two workgroups that take runs of three table windows in turn; a budget of
+# 1 MiB for the window table, so that the products of the larger test matrices fall back to the slab order on their own
+# while the small ones keep the table.
 PLANS = {
     "default": {},
     "dense_all": {"SPMM_DENSE_MIN": "1"},
@@ -48,6 +51,10 @@ PLANS = {
     "sorted_rows_up_to_512": {"SPMM_ESC_MAX": "512"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
     "small_cursor_workgroups_one_level": {"SPMM_LIGHT_MAX": "65535", "SPMM_LIGHT_TWO": "0", "SPMM_LIGHT_SYM": "0"},
+    "rows_not_shared": {"SPMM_SPLIT_GIANT": "0"},
+    "split_rows_two_workgroups": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8", "SPMM_GIANT_MAJOR": "0", "SPMM_GIANT_TASKS": "2",
+                                  "SPMM_GIANT_CHUNK": "3"},
+    "table_budget_falls_back_to_slab": {"SPMM_TABLE_MAX_MIB": "1"},
 }
 
 
@@ -67,6 +74,26 @@ def ctx(request):
                 os.environ[k] = v
     yield c
     c.close()
+
+
+@pytest.mark.parametrize("name,value", [("SPMM_GIANT_TASKS", "1"), ("SPMM_GIANT_TASKS", "x"), ("SPMM_MAJOR_CHUNK", "6"), ("SPMM_ESC_MAX", "100000"),
+                                        ("SPMM_SLAB_THREADS", "384"), ("SPMM_DENSE_SPARSE", "-1"), ("SPMM_LIGHT_MAX", "12abc"),
+                                        ("SPMM_MAX_GRID_THREADS", "5000000000"), ("SPMM_SLAB", "2")])
+def test_switch_outside_its_range_fails_the_context(name, value):
+    """A kernel-selection switch that is not a number or lies outside the range its path was written for is an error of
+    spmm_ctx_create (SPMM_E_ARG), not a silently clamped or wrapped setting."""
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        with pytest.raises(capi.SpmmError) as e:
+            capi.Context(0)
+        assert e.value.code == -1 and name in str(e.value)
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
 
 
 def _ones_csr(n, row, col):
@@ -516,6 +543,24 @@ def test_product_rejects_unsorted_b(ctx):
     with pytest.raises(capi.SpmmError) as e:
         ctx.spgemm_symbolic(A)
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("bad_ip", [[0, 3, 2, 4], [0, 2, 5, 4], [-1, 2, 3, 4], [0, 2, 3, 9]])
+def test_product_rejects_broken_row_pointers(ctx, bad_ip):
+    """Row pointers that descend or point outside the entry arrays are an argument error, found by the structure
+    check before any kernel indexes the entries through them."""
+    rng = np.random.default_rng(5)
+    n = 3
+    ix = np.sort(rng.integers(0, n, 4)).astype(np.int32)
+    good = capi.Csr(n, n, np.array([0, 1, 3, 4], np.int32), np.array([0, 1, 2, 0], np.int32), np.ones(4))
+    bad = capi.Csr(n, n, np.array(bad_ip, np.int32), np.array([0, 1, 2, 0], np.int32), np.ones(4))
+    del ix
+    for A, B in ((bad, good), (good, bad)):
+        with pytest.raises(capi.SpmmError) as e:
+            ctx.spgemm_symbolic(A, B)
+        assert e.value.code == -1
+    c_ip, _, _ = ctx.spgemm_symbolic(good, good)        # the context still works afterwards
+    assert c_ip.tolist() == orc.spgemm_symbolic(n, n, good.indptr, good.indices, good.indptr, good.indices).tolist()
 
 
 def test_product_empty(ctx):
