@@ -252,10 +252,11 @@ class Context:
         _chk(lib().spmm_trace_formats(self._h, C.byref(va), C.c_int32(sect), C.c_int32(threshold), C.byref(o)))
         b, nk = o.bnum, o.n_keys
         out = dict(a)
-        out.update(bnum=b, bsize_list=a["bsize_list"][:b + 1].copy(), seq_offset=a["seq_offset"][:b + 1].copy(),
-                   panel_ptr=a["panel_ptr"][:b + 1].copy(), panel_list=a["panel_list"][:o.n_panel_entries].copy(),
-                   spv8_list=a["spv8_list"][:o.n_spv8].copy(), b_indptr=a["b_indptr"][:nrow + b].copy(),
-                   keys=a["keys"][:nk].copy(), seq_input=a["seq_input"][:nk].copy())
+        # (views of the worst-case buffers, not copies: keys and seq_input alone are hundreds of megabytes at scale 22)
+        out.update(bnum=b, bsize_list=a["bsize_list"][:b + 1], seq_offset=a["seq_offset"][:b + 1],
+                   panel_ptr=a["panel_ptr"][:b + 1], panel_list=a["panel_list"][:o.n_panel_entries],
+                   spv8_list=a["spv8_list"][:o.n_spv8], b_indptr=a["b_indptr"][:nrow + b],
+                   keys=a["keys"][:nk], seq_input=a["seq_input"][:nk])
         return out
 
     @staticmethod

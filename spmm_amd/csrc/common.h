@@ -91,8 +91,11 @@ struct slab_plan {
     uint32_t* cnt = nullptr;        // [window][slot] entries of C before this window in the slot's row
 };
 
+struct host_pool_buf { void* p; size_t bytes; bool used; };
+
 struct spmm_ctx {
     bool profile = false;
+    std::vector<host_pool_buf> host_pool;   // device arrays of the last host-pointer pre-processing call (preprocess.hip)
     plan_cache plan;
     slab_plan slab;
     int slab_wmax = 15360;          // widest column window (dense fp64 accumulators + flags in LDS)
@@ -139,6 +142,10 @@ struct spmm_ctx {
     int num_cu = 256;
     void* pinned = nullptr;   // small pinned host buffer for scalar read-backs
     size_t pinned_bytes = 0;
+    // xfer.hip: ring of pinned buffers and their events for the staged copies of the host-pointer entry points
+    void* xfer_ring = nullptr;
+    size_t xfer_ring_bytes = 0;
+    hipEvent_t xfer_ev[16] = {};
     // spmm_csr_from_coo_dev_noalloc: scratch requests are served from the static device array of noalloc.hip
     long long device_allocs = 0;          // hipMalloc calls this context has issued for its scratch slots
     void* scratch_ptr = nullptr;          // that array's address on this context's device
@@ -156,6 +163,11 @@ constexpr size_t SPMM_NOALLOC_SCRATCH_BYTES = (size_t)24 << 20;   // three sort 
 int noalloc_scratch_address(void** out);
 
 int ws_get(spmm_ctx* ctx, int slot, size_t bytes, void** out);
+
+// xfer.hip: a batch of copies between pageable host arrays and device memory, staged through pinned buffers by several
+// threads.  Host -> device: returns when the data is on the device; device -> host: when it is in the host arrays.
+struct xfer_item { void* host; void* dev; size_t bytes; };
+int xfer_batch(spmm_ctx* ctx, const std::vector<xfer_item>& items, bool to_device);
 
 // slab.hip: the heaviest rows of the product, one kernel launch per column window
 int slab_build(spmm_ctx* ctx, const spmm_csr* B);

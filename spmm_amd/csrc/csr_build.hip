@@ -87,18 +87,12 @@ extern "C" int spmm_csr_from_coo(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int3
     CHK(ws(ctx, WS_UP2, (size_t)nrow + 1, &d_ip));
     CHK(ws(ctx, WS_UP3, z, &d_ix));
     CHK(ws(ctx, WS_UP4, z, &d_data));
-    if (nnz) {
-        HIPCHK(hipMemcpyAsync(d_row, row, 4 * z, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(d_col, col, 4 * z, hipMemcpyHostToDevice, ctx->stream));
-    }
+    // copies staged through pinned buffers by several threads (xfer.hip)
+    CHK(xfer_batch(ctx, {{(void*)row, d_row, 4 * z}, {(void*)col, d_col, 4 * z}}, true));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     CHK(spmm_csr_from_coo_dev(ctx, nrow, ncol, nnz, d_row, d_col, d_ip, d_ix, d_data));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(indptr, d_ip, 4 * ((size_t)nrow + 1), hipMemcpyDeviceToHost, ctx->stream));
-    if (nnz) {
-        HIPCHK(hipMemcpyAsync(indices, d_ix, 4 * z, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(data, d_data, 8 * z, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    CHK(xfer_batch(ctx, {{indptr, d_ip, 4 * ((size_t)nrow + 1)}, {indices, d_ix, 4 * z}, {data, d_data, 8 * z}}, false));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);

@@ -147,9 +147,12 @@ extern "C" int spmm_ctx_destroy(spmm_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int i = 0; i < WS_NSLOTS; i++)
         if (c->slot[i]) hipFree(c->slot[i]);
+    for (host_pool_buf& b : c->host_pool) hipFree(b.p);
     for (auto& r : c->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto& r : c->free_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     if (c->pinned) hipHostFree(c->pinned);
+    if (c->xfer_ring) hipHostFree(c->xfer_ring);
+    for (hipEvent_t e : c->xfer_ev) if (e) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);

@@ -13,6 +13,7 @@
 // std::sort (bitmap.h:50) leaves ties in an implementation-defined order; everything that does
 // not depend on ties is identical to it.
 #include "common.h"
+#include <chrono>
 #include <climits>
 
 namespace {
@@ -967,21 +968,46 @@ int dev_wbseq(spmm_ctx* ctx, int32_t nrow, const int32_t* seq_bitmap, const int3
 // ===========================================================================
 // C ABI: the whole pipeline with host arrays
 namespace {
+// Device arrays of one host-pointer call.  They come from a cache in the context that holds the buffers of the LAST such
+// call: a request takes the smallest cached buffer that is large enough and not in use, or allocates; when the call
+// ends, its buffers stay cached and whatever it did not use is freed.  Repeated calls on inputs of one size therefore
+// allocate nothing, and the cache never holds more than one call's worth.
+struct PoolGuard {
+    spmm_ctx* ctx = nullptr;
+    std::vector<void*> pool;   // (kept for the call sites: the buffers this call took)
+    ~PoolGuard() {
+        if (!ctx) return;
+        std::vector<host_pool_buf> keep;
+        bool freed = false;
+        for (host_pool_buf& b : ctx->host_pool) {
+            if (b.used) { b.used = false; keep.push_back(b); }
+            else { if (!freed) { hipStreamSynchronize(ctx->stream); freed = true; } hipFree(b.p); }
+        }
+        ctx->host_pool.swap(keep);
+    }
+};
 template <typename T>
-int dalloc(std::vector<void*>& pool, size_t count, T** out) {
+int dalloc(PoolGuard& g, spmm_ctx* ctx, size_t count, T** out) {
+    g.ctx = ctx;
+    const size_t bytes = (count + 1) * sizeof(T);
+    host_pool_buf* best = nullptr;
+    for (host_pool_buf& b : ctx->host_pool)
+        if (!b.used && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best && best->bytes <= 2 * bytes + 4096) {
+        best->used = true;
+        *out = (T*)best->p;
+        return SPMM_OK;
+    }
     void* p = nullptr;
-    if (hipMalloc(&p, (count + 1) * sizeof(T)) != hipSuccess) {
-        spmm_set_error("hipMalloc of %zu bytes failed", (count + 1) * sizeof(T));
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        spmm_set_error("hipMalloc of %zu bytes failed", bytes);
         return SPMM_E_HIP;
     }
-    pool.push_back(p);
+    ctx->device_allocs++;
+    ctx->host_pool.push_back({p, bytes, true});
     *out = (T*)p;
     return SPMM_OK;
 }
-struct PoolGuard {
-    std::vector<void*> pool;
-    ~PoolGuard() { for (void* p : pool) hipFree(p); }
-};
 template <typename T>
 int d2h(spmm_ctx* ctx, T* host, const T* dev, size_t count) {
     if (host && count) HIPCHK(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
@@ -1001,20 +1027,18 @@ extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect
     PoolGuard g;
     int32_t *a_ip, *a_ix, *seq_bitmap, *r_ip, *r_ix, *bsize;
     double *a_val, *r_val;
-    CHK(dalloc(g.pool, (size_t)n + 1, &a_ip));
-    CHK(dalloc(g.pool, z, &a_ix));
-    CHK(dalloc(g.pool, z, &a_val));
-    CHK(dalloc(g.pool, (size_t)n, &seq_bitmap));
-    CHK(dalloc(g.pool, (size_t)n + 1, &r_ip));
-    CHK(dalloc(g.pool, z, &r_ix));
-    CHK(dalloc(g.pool, z, &r_val));
+    CHK(dalloc(g, ctx, (size_t)n + 1, &a_ip));
+    CHK(dalloc(g, ctx, z, &a_ix));
+    CHK(dalloc(g, ctx, z, &a_val));
+    CHK(dalloc(g, ctx, (size_t)n, &seq_bitmap));
+    CHK(dalloc(g, ctx, (size_t)n + 1, &r_ip));
+    CHK(dalloc(g, ctx, z, &r_ix));
+    CHK(dalloc(g, ctx, z, &r_val));
     const int32_t cap = o->cap_blocks + 1;
-    CHK(dalloc(g.pool, (size_t)cap, &bsize));
-    HIPCHK(hipMemcpyAsync(a_ip, A->indptr, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (nnz) {
-        HIPCHK(hipMemcpyAsync(a_ix, A->indices, 4 * z, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(a_val, A->data, 8 * z, hipMemcpyHostToDevice, ctx->stream));
-    }
+    CHK(dalloc(g, ctx, (size_t)cap, &bsize));
+    const auto tt0 = std::chrono::steady_clock::now();
+    CHK(xfer_batch(ctx, {{(void*)A->indptr, a_ip, 4 * ((size_t)n + 1)}, {(void*)A->indices, a_ix, 4 * z}, {(void*)A->data, a_val, 8 * z}}, true));
+    const auto tt1 = std::chrono::steady_clock::now();
     spmm_csr dA = *A;
     dA.indptr = a_ip; dA.indices = a_ix; dA.data = a_val;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1025,26 +1049,26 @@ extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect
     int8_t* grp;
     int32_t *perm2, *g_ip, *b_indptr, *b_colidx, *b_local, *keys, *seq_offset, *seq_input, *rseq;
     double* b_data;
-    CHK(dalloc(g.pool, (size_t)bnum + 1, &P.panel_ptr));
-    CHK(dalloc(g.pool, (size_t)n / 8 + 3 * (size_t)bnum + 8, &P.panel_list));
-    CHK(dalloc(g.pool, (size_t)n / 8 + 3 * (size_t)bnum + 8, &P.spv8));
-    CHK(dalloc(g.pool, (size_t)n, &P.out_seq));
-    CHK(dalloc(g.pool, (size_t)n, &grp));
+    CHK(dalloc(g, ctx, (size_t)bnum + 1, &P.panel_ptr));
+    CHK(dalloc(g, ctx, (size_t)n / 8 + 3 * (size_t)bnum + 8, &P.panel_list));
+    CHK(dalloc(g, ctx, (size_t)n / 8 + 3 * (size_t)bnum + 8, &P.spv8));
+    CHK(dalloc(g, ctx, (size_t)n, &P.out_seq));
+    CHK(dalloc(g, ctx, (size_t)n, &grp));
     P.grp = grp;
     CHK(dev_panels(ctx, n, bnum, bsize, r_ip, &P));
-    CHK(dalloc(g.pool, (size_t)n, &perm2));
-    CHK(dalloc(g.pool, (size_t)n + 1, &g_ip));
-    CHK(dalloc(g.pool, (size_t)n + bnum, &b_indptr));
-    CHK(dalloc(g.pool, z, &b_colidx));
-    CHK(dalloc(g.pool, z, &b_data));
+    CHK(dalloc(g, ctx, (size_t)n, &perm2));
+    CHK(dalloc(g, ctx, (size_t)n + 1, &g_ip));
+    CHK(dalloc(g, ctx, (size_t)n + bnum, &b_indptr));
+    CHK(dalloc(g, ctx, z, &b_colidx));
+    CHK(dalloc(g, ctx, z, &b_data));
     CHK(dev_pack(ctx, n, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, b_indptr, b_colidx, b_data));
-    CHK(dalloc(g.pool, z, &b_local));
-    CHK(dalloc(g.pool, z, &keys));
-    CHK(dalloc(g.pool, (size_t)bnum + 1, &seq_offset));
+    CHK(dalloc(g, ctx, z, &b_local));
+    CHK(dalloc(g, ctx, z, &keys));
+    CHK(dalloc(g, ctx, (size_t)bnum + 1, &seq_offset));
     int32_t nkeys = 0;
     CHK(dev_first_touch(ctx, A->ncol, nnz, bnum, bsize, r_ip, b_colidx, b_local, keys, seq_offset, &nkeys));
-    CHK(dalloc(g.pool, (size_t)nkeys, &seq_input));
-    CHK(dalloc(g.pool, (size_t)n, &rseq));
+    CHK(dalloc(g, ctx, (size_t)nkeys, &seq_input));
+    CHK(dalloc(g, ctx, (size_t)n, &rseq));
     CHK(dev_wbseq(ctx, n, seq_bitmap, perm2, keys, nkeys, seq_input, rseq));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     // download
@@ -1052,23 +1076,34 @@ extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect
     o->n_keys = nkeys;
     o->n_panel_entries = P.n_list;
     o->n_spv8 = P.npanel;
-    CHK(d2h(ctx, o->seq_bitmap, seq_bitmap, (size_t)n));
-    CHK(d2h(ctx, o->r_indptr, r_ip, (size_t)n + 1));
-    CHK(d2h(ctx, o->r_indices, r_ix, z));
-    CHK(d2h(ctx, o->r_data, r_val, z));
-    CHK(d2h(ctx, o->bsize_list, bsize, (size_t)bnum + 1));
-    CHK(d2h(ctx, o->seq_offset, seq_offset, (size_t)bnum + 1));
-    CHK(d2h(ctx, o->panel_ptr, P.panel_ptr, (size_t)bnum + 1));
-    CHK(d2h(ctx, o->panel_list, P.panel_list, (size_t)P.n_list));
-    CHK(d2h(ctx, o->spv8_list, P.spv8, (size_t)P.npanel));
-    CHK(d2h(ctx, o->out_seq_all, P.out_seq, (size_t)n));
-    CHK(d2h(ctx, o->b_indptr, b_indptr, (size_t)n + bnum));
-    CHK(d2h(ctx, o->b_colidx_orig, b_colidx, z));
-    CHK(d2h(ctx, o->b_local, b_local, z));
-    CHK(d2h(ctx, o->b_data, b_data, z));
-    CHK(d2h(ctx, o->keys, keys, (size_t)nkeys));
-    CHK(d2h(ctx, o->seq_input, seq_input, (size_t)nkeys));
-    CHK(d2h(ctx, o->rseq, rseq, (size_t)n));
+    {
+        std::vector<xfer_item> out;
+        auto add = [&](void* host, const void* dev, size_t bytes) { if (host && bytes) out.push_back({host, (void*)dev, bytes}); };
+        add(o->seq_bitmap, seq_bitmap, 4 * (size_t)n);
+        add(o->r_indptr, r_ip, 4 * ((size_t)n + 1));
+        add(o->r_indices, r_ix, 4 * z);
+        add(o->r_data, r_val, 8 * z);
+        add(o->bsize_list, bsize, 4 * ((size_t)bnum + 1));
+        add(o->seq_offset, seq_offset, 4 * ((size_t)bnum + 1));
+        add(o->panel_ptr, P.panel_ptr, 4 * ((size_t)bnum + 1));
+        add(o->panel_list, P.panel_list, 4 * (size_t)P.n_list);
+        add(o->spv8_list, P.spv8, 4 * (size_t)P.npanel);
+        add(o->out_seq_all, P.out_seq, 4 * (size_t)n);
+        add(o->b_indptr, b_indptr, 4 * ((size_t)n + bnum));
+        add(o->b_colidx_orig, b_colidx, 4 * z);
+        add(o->b_local, b_local, 4 * z);
+        add(o->b_data, b_data, 8 * z);
+        add(o->keys, keys, 4 * (size_t)nkeys);
+        add(o->seq_input, seq_input, 4 * (size_t)nkeys);
+        add(o->rseq, rseq, 4 * (size_t)n);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const auto tt2 = std::chrono::steady_clock::now();
+        CHK(xfer_batch(ctx, out, false));
+        const auto tt3 = std::chrono::steady_clock::now();
+        if (getenv("SPMM_XFER_TRACE"))
+            fprintf(stderr, "trace_formats: upload %.1f ms, kernels %.1f ms, download %.1f ms\n", std::chrono::duration<double, std::milli>(tt1 - tt0).count(),
+                    std::chrono::duration<double, std::milli>(tt2 - tt1).count(), std::chrono::duration<double, std::milli>(tt3 - tt2).count());
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -1080,8 +1115,8 @@ extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect
 // C ABI: the stages one by one with host arrays
 namespace {
 template <typename T>
-int h2d_new(spmm_ctx* ctx, std::vector<void*>& pool, const T* host, size_t count, T** dev) {
-    CHK(dalloc(pool, count, dev));
+int h2d_new(spmm_ctx* ctx, PoolGuard& g, const T* host, size_t count, T** dev) {
+    CHK(dalloc(g, ctx, count, dev));
     if (count) HIPCHK(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return SPMM_OK;
 }
@@ -1109,15 +1144,15 @@ extern "C" int spmm_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sec
     PoolGuard g;
     int32_t *a_ip, *a_ix, *d_seq, *r_ip, *r_ix;
     double *a_val, *r_val;
-    CHK(h2d_new(ctx, g.pool, A->indptr, n + 1, &a_ip));
-    CHK(h2d_new(ctx, g.pool, A->indices, z, &a_ix));
-    CHK(h2d_new(ctx, g.pool, A->data, z, &a_val));
+    CHK(h2d_new(ctx, g, A->indptr, n + 1, &a_ip));
+    CHK(h2d_new(ctx, g, A->indices, z, &a_ix));
+    CHK(h2d_new(ctx, g, A->data, z, &a_val));
     spmm_csr dA = *A;
     dA.indptr = a_ip; dA.indices = a_ix; dA.data = a_val;
-    CHK(dalloc(g.pool, n, &d_seq));
-    CHK(dalloc(g.pool, n + 1, &r_ip));
-    CHK(dalloc(g.pool, z, &r_ix));
-    CHK(dalloc(g.pool, z, &r_val));
+    CHK(dalloc(g, ctx, n, &d_seq));
+    CHK(dalloc(g, ctx, n + 1, &r_ip));
+    CHK(dalloc(g, ctx, z, &r_ix));
+    CHK(dalloc(g, ctx, z, &r_val));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     CHK(dev_bitmap_reorder(ctx, &dA, sect, d_seq, r_ip, r_ix, r_val));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1136,9 +1171,9 @@ extern "C" int spmm_gen_blocks(spmm_ctx* ctx, const spmm_csr* R, int32_t thresho
     const size_t n = (size_t)R->nrow, z = (size_t)R->nnz;
     PoolGuard g;
     int32_t *r_ip, *r_ix, *bsize;
-    CHK(h2d_new(ctx, g.pool, R->indptr, n + 1, &r_ip));
-    CHK(h2d_new(ctx, g.pool, R->indices, z, &r_ix));
-    CHK(dalloc(g.pool, (size_t)cap, &bsize));
+    CHK(h2d_new(ctx, g, R->indptr, n + 1, &r_ip));
+    CHK(h2d_new(ctx, g, R->indices, z, &r_ix));
+    CHK(dalloc(g, ctx, (size_t)cap, &bsize));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     CHK(dev_gen_blocks(ctx, R->nrow, R->ncol, R->nnz, r_ip, r_ix, threshold, bsize, cap, bnum));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1157,25 +1192,25 @@ extern "C" int spmm_panels_sort_pack(spmm_ctx* ctx, const spmm_csr* R, const int
     PoolGuard g;
     int32_t *r_ip, *r_ix, *bsize;
     double* r_val;
-    CHK(h2d_new(ctx, g.pool, R->indptr, n + 1, &r_ip));
-    CHK(h2d_new(ctx, g.pool, R->indices, z, &r_ix));
-    CHK(h2d_new(ctx, g.pool, R->data, z, &r_val));
-    CHK(h2d_new(ctx, g.pool, bsize_list, (size_t)bnum + 1, &bsize));
+    CHK(h2d_new(ctx, g, R->indptr, n + 1, &r_ip));
+    CHK(h2d_new(ctx, g, R->indices, z, &r_ix));
+    CHK(h2d_new(ctx, g, R->data, z, &r_val));
+    CHK(h2d_new(ctx, g, bsize_list, (size_t)bnum + 1, &bsize));
     PanelsDev P;
     int8_t* grp;
     int32_t *perm2, *g_ip, *d_bip, *d_bix;
     double* d_bval;
-    CHK(dalloc(g.pool, (size_t)bnum + 1, &P.panel_ptr));
-    CHK(dalloc(g.pool, n / 8 + 3 * (size_t)bnum + 8, &P.panel_list));
-    CHK(dalloc(g.pool, n / 8 + 3 * (size_t)bnum + 8, &P.spv8));
-    CHK(dalloc(g.pool, n, &P.out_seq));
-    CHK(dalloc(g.pool, n, &grp));
+    CHK(dalloc(g, ctx, (size_t)bnum + 1, &P.panel_ptr));
+    CHK(dalloc(g, ctx, n / 8 + 3 * (size_t)bnum + 8, &P.panel_list));
+    CHK(dalloc(g, ctx, n / 8 + 3 * (size_t)bnum + 8, &P.spv8));
+    CHK(dalloc(g, ctx, n, &P.out_seq));
+    CHK(dalloc(g, ctx, n, &grp));
     P.grp = grp;
-    CHK(dalloc(g.pool, n, &perm2));
-    CHK(dalloc(g.pool, n + 1, &g_ip));
-    CHK(dalloc(g.pool, n + (size_t)bnum, &d_bip));
-    CHK(dalloc(g.pool, z, &d_bix));
-    CHK(dalloc(g.pool, z, &d_bval));
+    CHK(dalloc(g, ctx, n, &perm2));
+    CHK(dalloc(g, ctx, n + 1, &g_ip));
+    CHK(dalloc(g, ctx, n + (size_t)bnum, &d_bip));
+    CHK(dalloc(g, ctx, z, &d_bix));
+    CHK(dalloc(g, ctx, z, &d_bval));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     CHK(dev_panels(ctx, R->nrow, bnum, bsize, r_ip, &P));
     CHK(dev_pack(ctx, R->nrow, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, d_bip, d_bix, d_bval));
@@ -1201,12 +1236,12 @@ extern "C" int spmm_first_touch(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32
     const size_t n = (size_t)nrow, z = (size_t)nnz;
     PoolGuard g;
     int32_t *r_ip, *bsize, *stream, *d_local, *d_keys, *d_off;
-    CHK(h2d_new(ctx, g.pool, r_indptr, n + 1, &r_ip));
-    CHK(h2d_new(ctx, g.pool, bsize_list, (size_t)bnum + 1, &bsize));
-    CHK(h2d_new(ctx, g.pool, b_colidx_orig, z, &stream));
-    CHK(dalloc(g.pool, z, &d_local));
-    CHK(dalloc(g.pool, z, &d_keys));
-    CHK(dalloc(g.pool, (size_t)bnum + 1, &d_off));
+    CHK(h2d_new(ctx, g, r_indptr, n + 1, &r_ip));
+    CHK(h2d_new(ctx, g, bsize_list, (size_t)bnum + 1, &bsize));
+    CHK(h2d_new(ctx, g, b_colidx_orig, z, &stream));
+    CHK(dalloc(g, ctx, z, &d_local));
+    CHK(dalloc(g, ctx, z, &d_keys));
+    CHK(dalloc(g, ctx, (size_t)bnum + 1, &d_off));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     CHK(dev_first_touch(ctx, ncol, nnz, bnum, bsize, r_ip, stream, d_local, d_keys, d_off, n_keys));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1230,13 +1265,13 @@ extern "C" int spmm_wbseq(spmm_ctx* ctx, int32_t nrow, const int32_t* seq_bitmap
     const size_t n = (size_t)nrow;
     PoolGuard g;
     int32_t *d_seq, *d_out, *bsize, *d_keys, *perm2, *d_in, *d_rseq;
-    CHK(h2d_new(ctx, g.pool, seq_bitmap, n, &d_seq));
-    CHK(h2d_new(ctx, g.pool, out_seq_all, n, &d_out));
-    CHK(h2d_new(ctx, g.pool, bsize_list, (size_t)bnum + 1, &bsize));
-    CHK(h2d_new(ctx, g.pool, keys, (size_t)n_keys, &d_keys));
-    CHK(dalloc(g.pool, n, &perm2));
-    CHK(dalloc(g.pool, (size_t)n_keys, &d_in));
-    CHK(dalloc(g.pool, n, &d_rseq));
+    CHK(h2d_new(ctx, g, seq_bitmap, n, &d_seq));
+    CHK(h2d_new(ctx, g, out_seq_all, n, &d_out));
+    CHK(h2d_new(ctx, g, bsize_list, (size_t)bnum + 1, &bsize));
+    CHK(h2d_new(ctx, g, keys, (size_t)n_keys, &d_keys));
+    CHK(dalloc(g, ctx, n, &perm2));
+    CHK(dalloc(g, ctx, (size_t)n_keys, &d_in));
+    CHK(dalloc(g, ctx, n, &d_rseq));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     if (nrow > 0) hipLaunchKernelGGL(k_perm2, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, d_out, bsize, bnum, perm2);
     CHK(dev_wbseq(ctx, nrow, d_seq, perm2, d_keys, n_keys, d_in, d_rseq));

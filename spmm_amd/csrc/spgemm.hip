@@ -3546,11 +3546,8 @@ int upload_csr(spmm_ctx* ctx, const spmm_csr* M, int slot0, spmm_csr* d) {
     CHK(ws(ctx, slot0, (size_t)M->nrow + 1, &ip));
     CHK(ws(ctx, slot0 + 1, (size_t)M->nnz + 1, &ix));
     CHK(ws(ctx, slot0 + 2, (size_t)M->nnz + 1, &v));
-    HIPCHK(hipMemcpyAsync(ip, M->indptr, 4 * ((size_t)M->nrow + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (M->nnz) {
-        HIPCHK(hipMemcpyAsync(ix, M->indices, 4 * (size_t)M->nnz, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(v, M->data, 8 * (size_t)M->nnz, hipMemcpyHostToDevice, ctx->stream));
-    }
+    CHK(xfer_batch(ctx, {{(void*)M->indptr, ip, 4 * ((size_t)M->nrow + 1)}, {(void*)M->indices, ix, 4 * (size_t)M->nnz},
+                         {(void*)M->data, v, 8 * (size_t)M->nnz}}, true));
     *d = *M;
     d->indptr = ip;
     d->indices = ix;
@@ -3607,8 +3604,7 @@ extern "C" int spmm_spgemm_numeric(spmm_ctx* ctx, const spmm_csr* A, const spmm_
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (nz > 0) {
         ARGCHK(c_indices != nullptr && c_data != nullptr);
-        HIPCHK(hipMemcpyAsync(c_indices, d_cix, 4 * (size_t)nz, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(c_data, d_cv, 8 * (size_t)nz, hipMemcpyDeviceToHost, ctx->stream));
+        CHK(xfer_batch(ctx, {{c_indices, d_cix, 4 * (size_t)nz}, {c_data, d_cv, 8 * (size_t)nz}}, false));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
