@@ -225,6 +225,10 @@ def main():
            ("dense_num", capi.PH_DENSE_NUM), ("light_num", capi.PH_LIGHT_NUM), ("dense_sym", capi.PH_DENSE_SYM),
            ("slab_plan", capi.PH_SLAB_PLAN)]}
     ctx.profile(False)
+    # one more step, untimed, with the sum check: the timed steps reuse what the library keeps between steps
+    if os.environ.get("SPMM_BENCH_NOCHECK") != "1":
+        vsum, _ = step(verify=True)
+        assert vsum == float(P_local), f"rank {rank}: after the timed steps sum(C) = {vsum} but the rows hold {P_local} products"
     stamps = None
     if os.environ.get("SPMM_WIN_STAMPS") in ("1", "2", "3", "4"):
         st = ctx.debug_stamps().astype(np.float64)

@@ -3019,9 +3019,12 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
             hipLaunchKernelGGL(k_val_digest, dim3((unsigned)g), dim3(256), 0, ctx->stream, B->data, (int64_t)B->nnz, dg + CNT_DIG_VAL);
         }
     }
+    // A symbolic call on the matrices of the kept plan (the next step of an iteration over one pair of matrices) keeps
+    // what depends on the structure alone, the row products and the window table of B, and only classifies its rows and
+    // counts again; a numeric call also keeps the symbolic call's numbering and counts.
     bool hit = false;
-    if (!fresh && pc.valid && pc.slab == slab && pc.a_nrow == A->nrow && pc.a_nnz == A->nnz && pc.b_nrow == B->nrow &&
-        pc.b_ncol == B->ncol && pc.b_nnz == B->nnz) {
+    if ((mode == BINS_NUMERIC || (mode == BINS_SYMBOLIC && !slab)) && pc.valid && pc.slab == slab && pc.a_nrow == A->nrow &&
+        pc.a_nnz == A->nnz && pc.b_nrow == B->nrow && pc.b_ncol == B->ncol && pc.b_nnz == B->nnz) {
         HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (same) h[CNT_DIG_A] = h[CNT_DIG_B];
@@ -3055,7 +3058,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     if (slab) giant_mode = hit ? 2 : 1;
     else giant_mode = fresh ? (can_count ? 1 : 0) : (hit && pc.has_wcnt ? 2 : 0);
     if (mode == BINS_PRODUCTS) giant_mode = 0;
-    if (!hit) {
+    if (!hit || fresh) {   // a symbolic call numbers and counts the shared rows anew
         pc.has_wcnt = false;
         pc.n_giant = 0;
     }

@@ -368,6 +368,21 @@ def test_plan_of_another_matrix_is_not_reused_host(ctx):
     assert np.array_equal(ci, outs[1][1][c[1][r0]:c[1][r1]]) and np.array_equal(cd, outs[1][2][c[1][r0]:c[1][r1]])
 
 
+def test_repeated_steps_keep_the_plan_and_stay_exact(ctx):
+    """symbolic, numeric (in two row blocks), symbolic, numeric on ONE pair of matrices, as the steps of the benchmark
+    do: the second symbolic call keeps the row products and the window table of the first (content digests equal) and
+    counts again; then the other matrix of the same shape in between (a miss), and the first once more."""
+    n, mats, outs = _same_shape_pair()
+    A = [capi.Csr(n, n, *m) for m in mats]
+    for k in (0, 0, 1, 0, 0):
+        c_ip, nnz_c, _ = ctx.spgemm_symbolic(A[k])
+        assert np.array_equal(c_ip, outs[k][0]) and nnz_c == int(outs[k][0][-1])
+        mid = n // 2
+        for r0, r1 in ((0, mid), (mid, n)):
+            ci, cd = ctx.spgemm_numeric(A[k], None, c_ip, r0, r1)
+            assert np.array_equal(ci, outs[k][1][c_ip[r0]:c_ip[r1]]) and np.array_equal(cd, outs[k][2][c_ip[r0]:c_ip[r1]])
+
+
 def test_plan_of_another_matrix_is_not_reused_dev_refill(ctx):
     """The same through the device-pointer API with the matrices refilled IN PLACE between the calls: the pointers,
     shapes and sizes of every call are identical, only the contents differ."""
