@@ -32,6 +32,22 @@ from spmm_amd import capi, shard  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
 
 
+def source_digest():
+    """Digest of the library's sources (kernels, shared header, C ABI, build flags): identifies the build a profile
+    under profiles/ was taken from; the sources travel with every run, the git history does not."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "spmm_amd", "csrc", "*.hip"))) + [
+        os.path.join(ROOT, "spmm_amd", "csrc", "common.h"), os.path.join(ROOT, "spmm_amd", "csrc", "Makefile"),
+        os.path.join(ROOT, "include", "spmm_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def rmat_torch(scale, edge_factor, seed, device, row_lo=None, row_hi=None):
     """Graph500 R-MAT (a,b,c,d = .57,.19,.19,.05), level l decides bit l, no scrambling; dedup and
     (col,row) order like a SuiteSparse file.  Philox stream of torch, seeded.  With row_lo/row_hi only the
@@ -302,17 +318,22 @@ def main():
     # HBM bytes per launch from PMC counters cannot be collected inside this process: they come from
     # separate rocprofv3 --pmc passes over this same command, stored under profiles/ per workload.
     workload = f"R-MAT scale {args.scale} edge factor {args.edge_factor} seed {args.seed}, C=A*A, all values 1.0"
-    traffic = None
+    # A traffic figure is only taken from a profile of THIS build (same digest of the library's sources); a profile of
+    # another build is named, not used.
+    traffic, traffic_profile = None, None
     import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic*.json"))):
+    build = source_digest()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
         try:
             T = json.load(open(f))
             if T.get("workload") == workload and kname in T.get("kernels", {}) and world == 1:
-                traffic = T["kernels"][kname]["hbm_bytes_per_launch"]
+                same_build = T.get("source_digest") == build
+                traffic_profile = dict(file=os.path.basename(f), source_digest=T.get("source_digest"), same_build=same_build)
+                traffic = T["kernels"][kname]["hbm_bytes_per_launch"] if same_build else None
         except (OSError, ValueError, KeyError):
             pass
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_profile=traffic_profile, source_digest=build,
                     algorithmic_bytes_per_launch=bytes_w // max(launches, 1),
                     algorithmic_bytes_per_step=bytes_w, kernel_ms_per_step=round(t_w_ms, 3),
                     launches_per_step=launches, avg_launch_ms=round(t_w_ms / max(launches, 1), 5),
@@ -394,6 +415,34 @@ def main():
                    blocks=int(g["bnum"]), gpu_equals_oracle=bool(same),
                    what="spmm_trace_formats on the same matrix: bitmap reorder + blocks + panels + pack + renumber + write-back sequence")
         del g, o, A_h
+        # the compiled reference itself (oracle/_ref/libref.so, built from the reference's own sources where the
+        # reference tree was present) beside the GPU, on the same matrix WITH its diagonal: the reference's panel sort
+        # overflows a scratch array on matrices with empty rows (v8sort.h:157-160), and this graph has 2 million
+        from oracle import ref
+        if ref.available() and args.scale <= 22:
+            dg = torch.arange(n, dtype=torch.int64, device=dev)
+            rows_t = torch.repeat_interleave(dg, (indptr[1:] - indptr[:-1]).to(torch.int64))
+            keyd = torch.unique(torch.cat([indices.to(torch.int64) * n + rows_t, dg * n + dg]))   # (col, row) order, as the files
+            r_d, c_d = (keyd % n).to(torch.int32).cpu().numpy(), (keyd // n).to(torch.int32).cpu().numpy()
+            del keyd, rows_t, dg
+            M_d = ctx.csr_from_coo(n, n, r_d, c_d)
+            ctx.trace_formats(M_d)
+            tw = time.perf_counter()
+            gd = ctx.trace_formats(M_d)
+            wall_d = (time.perf_counter() - tw) * 1e3
+            gpu_d = ctx.last_kernel_ms()
+            ref.set_csr(n, M_d.indptr, M_d.indices, M_d.data)
+            tc = time.perf_counter()
+            rd = ref.trace_formats(n, int(M_d.indices.size))
+            ref_ms = (time.perf_counter() - tc) * 1e3
+            pre["reference"] = dict(kind="reference", cores=1, value_ms=round(ref_ms, 1),
+                                    matrix="the same matrix with its diagonal added (no empty rows)", nnz=int(M_d.indices.size),
+                                    gpu_ms=round(gpu_d, 2), gpu_wall_ms_host_arrays_in_and_out=round(wall_d, 1),
+                                    same_blocks=bool(np.array_equal(gd["bsize_list"], rd["bsize_list"]) and
+                                                     np.array_equal(gd["seq_offset"], rd["seq_offset"])),
+                                    what="gen_trace_formats of the compiled reference, its own stage timers' scope "
+                                         "(serial_newblock_clock.cpp:565), one thread")
+            del gd, rd, M_d
 
     out = dict(metric="spgemm_gflops", value=round(gflops, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
                warmup=max(args.warmup, 1), ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="strong",

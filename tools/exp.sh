@@ -1,1 +1,1 @@
-timeout -k 10 600 python -u -m pytest tests/test_gpu_spgemm.py -m gpu -x -q --timeout 120 --timeout-method thread -k "plan or repeated or values_changed or shared_by or golden" 2>&1 | tail -3 && tools/runvar.sh reuse 22 && tools/runvar.sh reuse24 24
+timeout -k 10 500 python bench.py > gpurun_out/bdef.json 2> gpurun_out/bdef.err; tail -c 2500 gpurun_out/bdef.json; tail -3 gpurun_out/bdef.err

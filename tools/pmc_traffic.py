@@ -46,7 +46,9 @@ for k in ("k_dense", "k_win<numeric>", "k_win<numeric, 256 threads>", "k_digest"
                           write_requests_per_launch=int(tot[k]["TCC_EA0_WRREQ_sum"] / m),
                           write_requests_64B_per_launch=int(tot[k]["TCC_EA0_WRREQ_64B_sum"] / m))
     kernels[k]["hbm_bytes_per_launch"] = int(rd + wr)
-print(json.dumps(dict(workload=workload, command=command,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (for the digest of the library's sources: bench.py takes a traffic figure only from a profile of its own build)
+print(json.dumps(dict(workload=workload, command=command, source_digest=bench.source_digest(),
                       note="rocprofv3 --pmc, separate passes; read bytes from the request-size split of TCC_EA0_RDREQ when that pass "
                            "was taken (32/64/128-byte requests), else FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64 "
                            "bytes); calibration: k_digest streams 12 B per entry of C once",
