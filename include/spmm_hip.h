@@ -219,6 +219,10 @@ int spmm_spv8_spmm(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
  *      call uploads its inputs, runs the stage on the GPU and downloads the outputs;
  *      spmm_last_kernel_ms() gives the kernel time of the last call.  Chaining them reproduces
  *      spmm_trace_formats, which keeps the intermediate arrays on the device instead. */
+/* The row keys of a3 alone (bitmap.h:123-146): keys[nrow], the bucket of every row.  What a rank of the row-sharded
+ * pipeline needs of its own rows before the global bucket order is known (spmm_amd/shard_pre.py). */
+int spmm_row_keys(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* keys);
+
 /* a3, replaces bitmap_reorder() (bitmap.h:108-170): row key per SECT-column section, stable bucket
  * by key, row gather.  seq[nrow] (new row -> old row), r_indptr[nrow+1], r_indices[nnz], r_data[nnz]
  * are caller-allocated. */

@@ -233,17 +233,19 @@ class Context:
                                           C.byref(n_out)))
         return Csr(nrow, ncol, ip, ix[:n_out.value].copy(), d[:n_out.value].copy())
 
-    def trace_formats(self, A, sect=2048, threshold=65536, cap_blocks=None):
-        """Returns a dict with every array the pipeline produces (names as in spmm_trace)."""
+    def trace_formats(self, A, sect=2048, threshold=65536, cap_blocks=None, guard=0):
+        """Returns a dict with every array the pipeline produces (names as in spmm_trace).  guard > 0 (tests): every
+        output array gets that many extra elements behind its worst-case size, filled with a sentinel, and the dict
+        also holds them as "_raw" for the caller to check that nothing wrote there."""
         nrow, nnz = A.nrow, A.nnz
         cap = cap_blocks if cap_blocks is not None else max(1, min(nrow + 1, 1 << 20))
-        a = dict(
-            seq_bitmap=np.empty(nrow, I32), r_indptr=np.empty(nrow + 1, I32), r_indices=np.empty(nnz, I32),
-            r_data=np.empty(nnz, F64), bsize_list=np.empty(cap + 1, I32), seq_offset=np.empty(cap + 1, I32),
-            panel_ptr=np.empty(cap + 1, I32), panel_list=np.empty(nrow // 8 + 3 * cap + 8, I32),
-            spv8_list=np.empty(nrow // 8 + 3 * cap + 8, I32), out_seq_all=np.empty(nrow, I32),
-            b_indptr=np.empty(nrow + cap, I32), b_colidx_orig=np.empty(nnz, I32), b_local=np.empty(nnz, I32),
-            b_data=np.empty(nnz, F64), keys=np.empty(nnz, I32), seq_input=np.empty(nnz, I32), rseq=np.empty(nrow, I32))
+        sizes = dict(seq_bitmap=(nrow, I32), r_indptr=(nrow + 1, I32), r_indices=(nnz, I32), r_data=(nnz, F64),
+                     bsize_list=(cap + 1, I32), seq_offset=(cap + 1, I32), panel_ptr=(cap + 1, I32),
+                     panel_list=(nrow // 8 + 3 * cap + 8, I32), spv8_list=(nrow // 8 + 3 * cap + 8, I32), out_seq_all=(nrow, I32),
+                     b_indptr=(nrow + cap, I32), b_colidx_orig=(nnz, I32), b_local=(nnz, I32), b_data=(nnz, F64), keys=(nnz, I32),
+                     seq_input=(nnz, I32), rseq=(nrow, I32))
+        raw = {k: (np.empty(n, t) if guard == 0 else np.full(n + guard, -77, t)) for k, (n, t) in sizes.items()}
+        a = {k: raw[k][:sizes[k][0]] for k in sizes}
         o = TraceOut()
         for k, v in a.items():
             setattr(o, k, v.ctypes.data)
@@ -257,6 +259,8 @@ class Context:
                    panel_ptr=a["panel_ptr"][:b + 1], panel_list=a["panel_list"][:o.n_panel_entries],
                    spv8_list=a["spv8_list"][:o.n_spv8], b_indptr=a["b_indptr"][:nrow + b],
                    keys=a["keys"][:nk], seq_input=a["seq_input"][:nk])
+        if guard:
+            out["_raw"] = raw
         return out
 
     @staticmethod
@@ -294,6 +298,13 @@ class Context:
         return Y
 
     # ---- the stages one by one (host arrays) ---------------------------------------
+    def row_keys(self, A, sect=2048):
+        """The bucket of every row (bitmap.h:123-146)."""
+        keys = np.empty(A.nrow, I32)
+        va = A.view()
+        _chk(lib().spmm_row_keys(self._h, C.byref(va), C.c_int32(sect), _p(keys)))
+        return keys
+
     def bitmap_reorder(self, A, sect=2048):
         """a3 (bitmap.h:108-170) -> (seq, Csr of the reordered matrix)."""
         seq = np.empty(A.nrow, I32)

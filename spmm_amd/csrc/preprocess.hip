@@ -740,6 +740,20 @@ int sort_stream_by_col(spmm_ctx* ctx, const int32_t* ix, int32_t nnz, int32_t nc
 // ===========================================================================
 // device-level stages (all pointers are device pointers)
 
+// keys[r] = bucket of row r (bitmap.h:123-146), device arrays
+int dev_row_keys(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, uint32_t* keys) {
+    const int32_t n = A->nrow;
+    if (n <= 0) return SPMM_OK;
+    int32_t *long_rows, *n_long;
+    CHK(ws(ctx, WS_MISC1, (size_t)n + 1, &long_rows));
+    CHK(ws(ctx, WS_COUNTERS, 64, &n_long));
+    HIPCHK(hipMemsetAsync(n_long, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, keys,
+                       long_rows, n_long);
+    hipLaunchKernelGGL(k_row_keys_long, dim3(1024), dim3(256), 0, ctx->stream, long_rows, n_long, A->indptr, A->indices, sect, keys);
+    return SPMM_OK;
+}
+
 int dev_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* seq, int32_t* r_ip, int32_t* r_ix, double* r_val) {
     const int32_t n = A->nrow;
     int ph = phase_begin(ctx, SPMM_PH_REORDER);
@@ -748,13 +762,7 @@ int dev_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* 
     CHK(ws(ctx, WS_RADIX_V0, (size_t)n + 1, &v0));
     CHK(ws(ctx, WS_RADIX_K1, (size_t)n + 1, &k1));
     if (n > 0) {
-        int32_t *long_rows, *n_long;
-        CHK(ws(ctx, WS_MISC1, (size_t)n + 1, &long_rows));
-        CHK(ws(ctx, WS_COUNTERS, 64, &n_long));
-        HIPCHK(hipMemsetAsync(n_long, 0, sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, k0,
-                           long_rows, n_long);
-        hipLaunchKernelGGL(k_row_keys_long, dim3(1024), dim3(256), 0, ctx->stream, long_rows, n_long, A->indptr, A->indices, sect, k0);
+        CHK(dev_row_keys(ctx, A, sect, k0));
         hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)n);
         CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, (uint32_t*)seq, n, bits_for((uint32_t)(A->ncol / sect))));
     }
@@ -1133,6 +1141,26 @@ int finish_timed(spmm_ctx* ctx) {
     return SPMM_OK;
 }
 }  // namespace
+
+extern "C" int spmm_row_keys(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* keys) {
+    ARGCHK(ctx != nullptr && keys != nullptr && sect > 0);
+    CHK(check_host_csr(A));
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)A->nrow, z = (size_t)A->nnz;
+    PoolGuard g;
+    int32_t *a_ip, *a_ix;
+    uint32_t* d_keys;
+    CHK(h2d_new(ctx, g, A->indptr, n + 1, &a_ip));
+    CHK(h2d_new(ctx, g, A->indices, z, &a_ix));
+    CHK(dalloc(g, ctx, n, &d_keys));
+    spmm_csr dA = *A;
+    dA.indptr = a_ip; dA.indices = a_ix; dA.data = nullptr;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    CHK(dev_row_keys(ctx, &dA, sect, d_keys));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    CHK(d2h(ctx, keys, (const int32_t*)d_keys, n));
+    return finish_timed(ctx);
+}
 
 extern "C" int spmm_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* seq, int32_t* r_indptr,
                                    int32_t* r_indices, double* r_data) {

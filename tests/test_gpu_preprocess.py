@@ -201,3 +201,35 @@ def test_spmm_over_the_packed_formats(ctx, nvec):
     np.testing.assert_allclose(Y, M @ Xr, rtol=1e-12, atol=1e-12)
     with pytest.raises(capi.SpmmError):
         ctx.spv8_spmm(T, n, np.zeros((n, 0)))
+
+
+class _OneRank:
+    """torch.distributed's calls for a world of one rank."""
+
+    @staticmethod
+    def all_gather_into_tensor(out, inp):
+        out.copy_(inp.reshape(out.shape))
+
+
+@pytest.mark.parametrize("threshold", [65536, 200])
+def test_sharded_pipeline_stages_on_the_gpu(threshold):
+    """spmm_amd/shard_pre.py with the GPU stages (GpuStages over the C ABI, spmm_row_keys among them) in a world of one
+    rank against spmm_trace_formats and the oracle; the exchanges between ranks are covered on the CPU over gloo
+    (tests/test_shard_pre_gloo.py)."""
+    from spmm_amd import shard_pre
+    n = 1 << 12
+    row, col = synth.rmat(12, 8, 21, diagonal=True)
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    c = capi.Context(0)
+    try:
+        assert np.array_equal(c.row_keys(capi.Csr(n, n, ip, ix, d), 256), orc.row_keys(ip, ix, 256))
+        S = shard_pre.trace_formats_sharded(shard_pre.GpuStages(c), _OneRank, 0, 1, n, n, ip, ix, d, 256, threshold)
+        T = c.trace_formats(capi.Csr(n, n, ip, ix, d), sect=256, threshold=threshold)
+    finally:
+        c.close()
+    W = orc.trace_formats(n, ip, ix, d, sect=256, threshold=threshold, sort_mode=1)
+    assert S["blocks"] == (0, W["bnum"])
+    for k in ("seq_bitmap", "r_indptr", "r_indices", "bsize_list", "panel_ptr", "panel_list", "spv8_list", "out_seq_all", "b_indptr",
+              "b_colidx_orig", "b_local", "keys", "seq_offset", "seq_input", "rseq"):
+        assert np.array_equal(S[k], W[k]), k
+        assert np.array_equal(T[k], W[k]), k
