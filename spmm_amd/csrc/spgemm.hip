@@ -46,9 +46,12 @@ constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14
 constexpr int WIN_SHIFT_MAX = 17;
 constexpr int KEY_PAD = 0x7fffffff;
 
-// B as 12-byte records {column id, value}: a short piece of a row of B (most pieces a window kernel reads hold a few
-// products) then lies in one cache line instead of one line of column ids and one of values.  Packed by every
-// numeric call (k_pack_b12) from the caller's arrays.
+// B as 12-byte records {value, column id}: a short piece of a row of B (most pieces a window kernel reads hold a few
+// products) then lies in one cache line instead of one line of column ids and one of values.  Packed by a numeric
+// call (k_pack_b12) from the caller's arrays.  The value comes FIRST: a 12-byte load lands in three consecutive
+// registers, and gfx950 takes a 64-bit operand only from an even-aligned register pair, so with the column id in front
+// every loaded value had to be moved to an aligned pair before its first use, and that move is a use of the load: loads
+// meant to stay in flight across a phase (the dense kernel's products of the next window) were waited for at once.
 struct colval { int col; double val; };
 // Pointers to global memory that say so in their type.  Inside a kernel the compiler infers the address space of the
 // kernel's pointer arguments; inside a function that is NOT inlined an ordinary pointer argument is a generic one, and
@@ -60,15 +63,15 @@ typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ colval ld_b12(gptr_cu32 b12, int pos) {
     const u32x3 r = *reinterpret_cast<const SPMM_GLOBAL u32x3*>(b12 + 3ull * (unsigned)pos);
     colval cv;
-    cv.col = (int)r.x;
-    cv.val = __hiloint2double((int)r.z, (int)r.y);
+    cv.col = (int)r.z;
+    cv.val = __hiloint2double((int)r.y, (int)r.x);
     return cv;
 }
 __device__ __forceinline__ colval ld_b12(const uint32_t* __restrict__ b12, int pos) {
     const uint3 r = *reinterpret_cast<const uint3*>(b12 + 3ull * (unsigned)pos);
     colval cv;
-    cv.col = (int)r.x;
-    cv.val = __hiloint2double((int)r.z, (int)r.y);
+    cv.col = (int)r.z;
+    cv.val = __hiloint2double((int)r.y, (int)r.x);
     return cv;
 }
 __global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_ix, const double* __restrict__ b_val, int64_t nnz,
@@ -77,9 +80,9 @@ __global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nnz; p += stride) {
         const double v = b_val[p];
         uint3 r;
-        r.x = (uint32_t)b_ix[p];
-        r.y = (uint32_t)__double2loint(v);
-        r.z = (uint32_t)__double2hiint(v);
+        r.x = (uint32_t)__double2loint(v);
+        r.y = (uint32_t)__double2hiint(v);
+        r.z = (uint32_t)b_ix[p];
         *reinterpret_cast<uint3*>(b12 + 3 * p) = r;
     }
 }
@@ -1051,6 +1054,7 @@ __device__ __forceinline__ void store_b128(SPMM_GLOBAL double* p, double a, doub
 // that cluster at low column ids over the waves.  Returns the number of entries of C written at c_ix / c_val.  Not
 // inlined: the cursor kernel runs at the register limit of 1024-thread workgroups, and this code's registers would
 // push its common path into spills (measured: 395 -> 458 ms).
+__device__ __forceinline__ int win_find(const int2* dir, int n, int p);
 template <int THREADS, int WORDS, int VALS, int PRE_BYTES>
 __device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, const uint32_t* __restrict__ b12_arg, int wbase,
                                                                    int32_t* __restrict__ c_ix_arg, double* __restrict__ c_val_arg) {
@@ -1076,20 +1080,41 @@ __device__ __noinline__ __attribute__((cold)) int win_dense_window(int flip, con
     int32_t* tmp = (int32_t*)(smem + tmp_off);
     if (tid < DENSE_COLS / 32) dflags[tid] = 0u;
     for (int i = tid; i < (int)(pre_bytes / 16); i += THREADS) ((uint4*)(smem + pre_off))[i] = make_uint4(0u, 0u, 0u, 0u);
-    const int e = lane * NW + wv;
-    const int2 de = dir[e];
-    const int len_e = dir[e + 1].x - de.x;
-    const double a_e = dir_av[e];
     __syncthreads();   // flags and rank prefixes cleared
-    wave_flat_sweep<true>(nullptr, b12, de.y, len_e, a_e, lane, wmap,
-                          [&](int col, double v, bool valid) {
-                              const unsigned lc = valid ? (unsigned)(col - wbase) : 0xffffffffu;
-                              if (lc < (unsigned)DENSE_COLS) {
-                                  atomicAdd(&acc[dense_slot(lc)], v);
-                                  atomicOr(&dflags[lc >> 5], 1u << (lc & 31));
-                              }
-                          },
-                          [] {});
+    // Every wave takes an equal share of the window's products, as a range of the flat index space the directory spans
+    // (pieces cut at the range's ends).  Whole entries dealt to the waves leave the window's one long piece, the part of
+    // a hub row of B below the first window boundary, often thousands of products, to a single wave while the others wait.
+    {
+        const int Tc = dir[THREADS].x;
+        const int share = ((Tc + NW - 1) / NW + 63) & ~63;
+        const int p0 = wv * share, p1 = p0 + share < Tc ? p0 + share : Tc;
+        if (p0 < p1) {
+            const int e0 = win_find(dir, THREADS, p0);
+            for (int eb = e0; eb < THREADS && dir[eb].x < p1; eb += 64) {   // wave-uniform
+                const int e = eb + lane;
+                int s_e = 0, rem_e = 0;
+                double a_e = 0.0;
+                if (e < THREADS) {
+                    const int2 de = dir[e];
+                    const int lo = de.x > p0 ? de.x : p0, nx = dir[e + 1].x, hi = nx < p1 ? nx : p1;
+                    if (hi > lo) {
+                        s_e = de.y + (lo - de.x);
+                        rem_e = hi - lo;
+                        a_e = dir_av[e];
+                    }
+                }
+                wave_flat_sweep<true>(nullptr, b12, s_e, rem_e, a_e, lane, wmap,
+                                      [&](int col, double v, bool valid) {
+                                          const unsigned lc = valid ? (unsigned)(col - wbase) : 0xffffffffu;
+                                          if (lc < (unsigned)DENSE_COLS) {
+                                              atomicAdd(&acc[dense_slot(lc)], v);
+                                              atomicOr(&dflags[lc >> 5], 1u << (lc & 31));
+                                          }
+                                      },
+                                      [] {});
+            }
+        }
+    }
     __syncthreads();
     // output: thread t owns columns [16t, 16t + 16) of the window, its 16 flag bits are half a word
     const unsigned m16 = ((const uint16_t*)dflags)[tid];
@@ -1316,7 +1341,8 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
         t_lo = T[0];
         if (NUMERIC) dir_av[tid] = a_val[a0 + tid];
     }
-    if (NUMERIC && adaptive) {
+    if (NUMERIC && adaptive)
+    for (int rep = (dbg & 0x40000) ? 0 : 1; rep < 2; rep++) {   // (diagnostic repeat of the table sums)
         for (int j = tid; j <= nh; j += THREADS) cs[j] = 0u;
         __syncthreads();
         // (entry, granule) pairs dealt to the waves 64 granules of one entry at a time, sixteen loads in flight per
@@ -1427,7 +1453,6 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                     s = t_lo;
                     len = t_hi - t_lo;
                     t_lo = t_hi;
-                    if (w1 < nbase) t_hi = T[w1_next];
                 }
             } else {
                 const int e = c0 + tid;
@@ -1484,6 +1509,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
                 // rows of B that cluster at low column ids over the waves.
                 if (dense_over && single_chunk && !fast && w1 - w0 == 1 && shift <= 14) {
                     // out of line, so that its registers do not weigh on the register-resident windows' allocation
+                    if (dbg & 0x80000) win_dense_window<THREADS, WORDS, VALS, (int)sizeof(pre_t)>(flip, b12, wbase, c_ix + out, c_val + out);   // (diagnostic repeat)
                     out += win_dense_window<THREADS, WORDS, VALS, (int)sizeof(pre_t)>(flip, b12, wbase, c_ix + out, c_val + out);
                     dense_done = true;
                     continue;   // leaves the chunk loop (a single-chunk row has one chunk)
@@ -1571,6 +1597,10 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 256 && TWO && WORDS <= 20
             }
         }
         WIN_STAMP(1)   // search + loads + bit atomics (this thread)
+        // The bound that ends the NEXT window is asked for here, behind the sweep's own loads, and is first used a rank
+        // prefix, a value phase and an output pass later.  (Asked for at the directory build, in front of the sweep, it was
+        // waited for right away: the compiler drains every outstanding load where the sweep's code begins.)
+        if (single_chunk && tid < lenA && w1 < nbase) t_hi = T[w1_next];
         if (dense_done) continue;   // the next directory build starts with a barrier
         if (Tw == 0) continue;
         WIN_ARRIVE(0)
@@ -2369,15 +2399,6 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                     }
                 }
             }
-            if (pipelined) {
-                // tier-1 loads of the next window stay in flight across the output pass (unconditional,
-                // see above; after the last window they read position 0)
-                const int len = w + 1 < nbase ? t_nxt - t_cur : 0;
-                const int q0 = pi < len ? t_cur + pi : 0, q1 = pi + LA < len ? t_cur + pi + LA : 0;
-                const colval c0 = ld_b12(b12, q0), c1 = ld_b12(b12, q1);
-                pb0 = c0.val; pb1 = c1.val;
-                pc0 = c0.col; pc1 = c1.col;
-            }
             DENSE_STAMP(0)
             __syncthreads();
             DENSE_STAMP(1)
@@ -2386,6 +2407,16 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
             // flag bytes are 0 or 1: the multiply gathers the four low bits of a word into bits 24..27
             const unsigned m16 = (((f.x * 0x01020408u) >> 24) & 0xfu) | ((((f.y * 0x01020408u) >> 24) & 0xfu) << 4) |
                                  ((((f.z * 0x01020408u) >> 24) & 0xfu) << 8) | ((((f.w * 0x01020408u) >> 24) & 0xfu) << 12);
+            if (pipelined) {
+                // tier-1 loads of the next window stay in flight across the output pass (unconditional,
+                // see above; after the last window they read position 0).  Issued behind the barrier and the read of
+                // the flags: in front of them the compiler drained the loads right after the barrier.
+                const int len = w + 1 < nbase ? t_nxt - t_cur : 0;
+                const int q0 = pi < len ? t_cur + pi : 0, q1 = pi + LA < len ? t_cur + pi + LA : 0;
+                const colval c0 = ld_b12(b12, q0), c1 = ld_b12(b12, q1);
+                pb0 = c0.val; pb1 = c1.val;
+                pc0 = c0.col; pc1 = c1.col;
+            }
             // sums leave LDS (and the slots are cleared) before the scan barrier, so the next sweep
             // can start right after it
             double vr[16];
