@@ -38,8 +38,8 @@ def source_digest():
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "spmm_amd", "csrc", "*.hip"))) + [
-        os.path.join(ROOT, "spmm_amd", "csrc", "common.h"), os.path.join(ROOT, "spmm_amd", "csrc", "Makefile"),
+    files = sorted(glob.glob(os.path.join(ROOT, "spmm_amd", "csrc", "*.hip"))) + sorted(glob.glob(os.path.join(ROOT, "spmm_amd", "csrc", "*.h"))) + [
+        os.path.join(ROOT, "spmm_amd", "csrc", "Makefile"),
         os.path.join(ROOT, "include", "spmm_hip.h")]
     for f in files:
         h.update(os.path.basename(f).encode())

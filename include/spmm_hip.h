@@ -93,6 +93,13 @@ int spmm_ctx_phase_ms(spmm_ctx* ctx, int phase, double* total_ms, int* launches)
  * by the 64-lane expand-sort-compress kernel, rows with at most *esc_large by the larger
  * expand-sort-compress kernels, heavier rows by the window kernels. */
 void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
+/* What a symbolic call keeps for the numeric calls that follow, and for the next symbolic call on the same matrices
+ * (row products, row lists, the window table of B or its slab order, B's 12-byte records), is reused when sizes and
+ * 64-bit content digests of the structure arrays (and of B's values, for the records) agree; the digests are the trust
+ * boundary of that reuse.  A caller that does not want to rely on them calls this between products: the next call of any
+ * kind then rebuilds everything from the arrays it is given.  No counterpart in the reference (it has no product). */
+int spmm_ctx_forget_plan(spmm_ctx* ctx);
+
 /* Plan parameters the context would use for a right-hand matrix with b_ncol columns: the window
  * table has *nbase windows of 2^*shift columns per row of B, and rows of A with at least
  * *dense_min_products intermediate products take the dense-accumulator numeric kernel (INT64_MAX

@@ -147,6 +147,10 @@ class Context:
         _chk(lib().spmm_debug_stamps(self._h, _p(out), C.c_int(1 if reset else 0)))
         return out
 
+    def forget_plan(self):
+        """Drop everything kept between the calls of a product (the next call rebuilds it from its own arrays)."""
+        _chk(lib().spmm_ctx_forget_plan(self._h))
+
     def plan_info(self, b_ncol):
         """(shift, nbase, dense_min_products) the context uses for a right-hand matrix of b_ncol columns."""
         sh, nb, dm = C.c_int32(), C.c_int32(), C.c_int64()

@@ -73,6 +73,17 @@ struct plan_cache {
     bool lists_valid = false;
     int l_row_beg = 0, l_row_end = 0;
     long long l_n_s = 0, l_n_t = 0, l_n_l = 0, l_n_m = 0, l_n_w = 0, l_n_g = 0, l_n_dense = 0, l_n_light = 0, l_products = 0, l_dense_entries = 0;
+
+    // A call that rebuilds the plan marks it untrusted first and trusted again only when it has run to its end, so that a
+    // call that fails half way leaves nothing a later call could take for a plan.
+    void begin_update() { valid = false; lists_valid = false; }
+    // Nothing kept is to be used again (spmm_ctx_forget_plan, a reallocated scratch slot): the next call of any kind
+    // computes row products, lists, the window table and B's records anew.
+    void invalidate() {
+        begin_update();
+        has_wcnt = has_table = has_slab = b12_valid = false;
+        n_giant = 0;
+    }
 };
 
 // B in slab order (slab.hip): column windows, entries sorted by window, pieces with links.

@@ -1,0 +1,515 @@
+// Sorting kernels of the product (expand / sort / compress in LDS): k_esc, k_esc_rows, k_escr.
+// Part of the one translation unit spgemm.hip (included there, in this order: spgemm_common.h, spgemm_esc.h,
+// spgemm_win.h, spgemm_dense.h, spgemm_sym.h); gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Expand / sort / compress in LDS, one row by the whole workgroup.
+template <int THREADS, int CAP, bool NUMERIC>
+__device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sval, int32_t* tmp,
+                                        const int32_t* __restrict__ a_ip,
+                                        const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                        const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                        const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                        const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                        int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    const int tid = threadIdx.x;
+    const int a0 = a_ip[row], a1 = a_ip[row + 1];
+    int64_t obase = 0;
+    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
+
+    int run = 0;
+    for (int e0 = a0; e0 < a1; e0 += THREADS) {
+        int p = e0 + tid, len = 0, b0 = 0;
+        double av = 0.0;
+        if (p < a1) {
+            int k = a_ix[p];
+            b0 = b_ip[k];
+            len = b_ip[k + 1] - b0;
+            if (NUMERIC) av = a_val[p];
+        }
+        int tot;
+        int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;
+        for (int q = 0; q < len; q++) {
+            skey[off + q] = b_ix[b0 + q];
+            if (NUMERIC) sval[off + q] = av * b_val[b0 + q];
+        }
+        run += tot;
+    }
+    int n2 = 1;
+    while (n2 < run) n2 <<= 1;
+    for (int i = run + tid; i < n2; i += THREADS) skey[i] = KEY_PAD;
+    __syncthreads();
+
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                bool up = (i & k) == 0;
+                int ki = skey[i], kl = skey[l];
+                if ((ki > kl) == up) {
+                    skey[i] = kl;
+                    skey[l] = ki;
+                    if (NUMERIC) { double x = sval[i]; sval[i] = sval[l]; sval[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    int outrun = 0;
+    for (int c0 = 0; c0 < n2; c0 += THREADS) {
+        int t = c0 + tid;
+        int key = t < n2 ? skey[t] : KEY_PAD;
+        bool head = key != KEY_PAD && (t == 0 || skey[t - 1] != key);
+        int tot;
+        int r = block_exclusive_scan<THREADS, int32_t>(head ? 1 : 0, tmp, &tot) + outrun;
+        if (NUMERIC && head) {
+            double s = sval[t];
+            for (int u = t + 1; u < n2 && skey[u] == key; u++) s += sval[u];
+            c_ix[obase + r] = key;
+            c_val[obase + r] = s;
+        }
+        outrun += tot;
+    }
+    if (!NUMERIC && tid == 0) rowcnt[row] = outrun;
+}
+
+template <int THREADS, int CAP, bool NUMERIC>
+__global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                 const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                                 const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                                 const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    __shared__ int32_t skey[CAP];
+    __shared__ double sval[NUMERIC ? CAP : 1];
+    __shared__ int32_t tmp[THREADS / 64 + 1];
+    esc_row<THREADS, CAP, NUMERIC>(list[blockIdx.x], skey, sval, tmp, a_ip, a_ix, a_val, b_ip, b_ix, b_val, rowcnt, c_ip, row_beg,
+                                   c_ix, c_val);
+}
+
+// The tiny rows of the smallest bin, 64/L per 64-lane workgroup.  Such a row is a chain of five dependent gathers
+// of a few dozen bytes each (list, row pointers of A, entries of A, row pointers of B, entries of B): latency, not
+// bandwidth, is its cost, so a row of at most QC products is expanded, sorted and compressed by L lanes in its
+// share of the LDS arrays and the wave keeps the chains of 64/L rows in flight.  (Measured and not kept: merging the
+// entries' ascending runs by rank, a binary search per product and other run, instead of the sorting network: the
+// searches are chains of dependent LDS reads, the network's stages are not; 0.43 + 0.82 -> 0.55 + 0.89 ms on a
+// web-Google-sized graph.)
+template <int L, int QC, bool NUMERIC>
+__global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ list, const int n_list, const int32_t* __restrict__ a_ip,
+                                             const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                             const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                             const double* __restrict__ b_val, int32_t* __restrict__ rowcnt, const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                             int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    static_assert(L == 8 || L == 16 || L == 32, "lanes per row");
+    static_assert(QC % L == 0, "whole rounds of products");
+    constexpr int R = 64 / L;             // rows per wave
+    constexpr int CAP = R * QC;
+    __shared__ int32_t skey[CAP];
+    __shared__ double sval[NUMERIC ? CAP : 1];
+    __shared__ int32_t eoff[R][L], eb0[R][L];
+    __shared__ double eav[NUMERIC ? R : 1][L];
+    const int lane = threadIdx.x, q = lane / L, ql = lane % L;
+    const int idx = blockIdx.x * R + q;
+    const bool small = idx < n_list;
+    const int row = small ? list[idx] : 0;
+    int a0 = 0, a1 = 0;
+    int64_t obase = 0;
+    if (small) {
+        a0 = a_ip[row];
+        a1 = a_ip[row + 1];
+        if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
+    }
+    int32_t* qkey = skey + q * QC;
+    double* qval = sval + (NUMERIC ? q * QC : 0);
+    // expand: the L lanes of a row have the same trip count, and the shuffles stay among them
+    int run = 0;
+    for (int e0 = a0; e0 < a1; e0 += L) {
+        const int p = e0 + ql;
+        int len = 0, b0 = 0;
+        double av = 0.0;
+        if (p < a1) {
+            const int k = a_ix[p];
+            b0 = b_ip[k];
+            len = b_ip[k + 1] - b0;
+            if (NUMERIC) av = a_val[p];
+        }
+        int inc = len;
+#pragma unroll
+        for (int d = 1; d < L; d <<= 1) {
+            const int t = __shfl_up(inc, d, L);
+            if (ql >= d) inc += t;
+        }
+        // the products of these L entries as one index space dealt round the L lanes: every lane finds the entry
+        // of its product among the L offsets, and its loads do not wait for one another (a lane walking its own
+        // row of B would pay one latency per product)
+        const int tot = __shfl(inc, L - 1, L);
+        eoff[q][ql] = inc - len;
+        eb0[q][ql] = b0;
+        if (NUMERIC) eav[NUMERIC ? q : 0][ql] = av;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < QC / L; i++) {
+            const int j = ql + L * i;
+            if (j < tot) {
+                int e = 0;
+#pragma unroll
+                for (int h = L / 2; h > 0; h >>= 1)
+                    if (eoff[q][e + h] <= j) e += h;       // the last entry that starts at or before product j
+                const int src = eb0[q][e] + (j - eoff[q][e]);
+                qkey[run + j] = b_ix[src];
+                if (NUMERIC) qval[run + j] = eav[NUMERIC ? q : 0][e] * b_val[src];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        run += tot;
+    }
+    int n2 = 0;
+    if (small) {
+        n2 = 1;
+        while (n2 < run) n2 <<= 1;
+        for (int i = run + ql; i < n2; i += L) qkey[i] = KEY_PAD;
+    }
+    int n2max = n2;
+#pragma unroll
+    for (int d = L; d < 64; d <<= 1) n2max = max(n2max, __shfl_xor(n2max, d));
+    __syncthreads();
+    // every row runs the stages of its own network; the barriers are those of the largest
+    for (int k = 2; k <= n2max; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (k <= n2) {
+                for (int t = ql; t < (n2 >> 1); t += L) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const bool up = (i & k) == 0;
+                    const int ki = qkey[i], kl = qkey[l];
+                    if ((ki > kl) == up) {
+                        qkey[i] = kl;
+                        qkey[l] = ki;
+                        if (NUMERIC) { const double x = qval[i]; qval[i] = qval[l]; qval[l] = x; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int outrun = 0;
+    for (int c0 = 0; c0 < n2max; c0 += L) {
+        const int t = c0 + ql;
+        const int key = t < n2 ? qkey[t] : KEY_PAD;
+        const bool head = key != KEY_PAD && (t == 0 || qkey[t - 1] != key);
+        const unsigned m = (unsigned)((__ballot(head) >> (q * L)) & ((1ull << L) - 1ull));
+        const int r = outrun + __popc(m & ((1u << ql) - 1u));
+        if (NUMERIC && head) {
+            double s = qval[t];
+            for (int u = t + 1; u < n2 && qkey[u] == key; u++) s += qval[u];
+            c_ix[obase + r] = key;
+            c_val[obase + r] = s;
+        }
+        outrun += __popc(m);
+    }
+    if (!NUMERIC && small && ql == 0) rowcnt[row] = outrun;
+}
+
+// ---------------------------------------------------------------------------
+// Expand / radix sort / compress in LDS for rows with up to CAP products, whatever their column
+// span (the window kernels pay per column window, and a light row of a wide matrix has few
+// products in each).  Products are expanded as (column id, index); the pairs go through a stable
+// LSD radix sort on 8-bit digits (per wave: ranks by ballot match and digit counters in LDS; per
+// workgroup: one scan over [digit][wave]); equal columns end adjacent.  Values are not carried
+// through the sort: the compress step reads a*b through the sorted index (position in B and entry
+// of A per product).
+#ifndef ESC_MERGE_MAX
+#define ESC_MERGE_MAX 4
+#endif
+template <int THREADS, int CAP, bool NUMERIC>
+__global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                  const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                  const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                                  const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val, int key_bits) {
+    constexpr int NW = THREADS / 64;
+    constexpr int EPT = CAP / THREADS;        // elements per thread
+    constexpr int CPW = CAP / NW;             // elements per wave in a sort pass
+    constexpr int QCAP = CAP / 64;            // entries with at least 64 products
+    static_assert(CPW == 64 * EPT && (256 * NW) % THREADS == 0, "geometry");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* key_a = (uint32_t*)smem;
+    uint32_t* key_b = key_a + CAP;
+    uint16_t* idx_a = (uint16_t*)(key_b + CAP);                 // NUMERIC
+    uint16_t* idx_b = idx_a + (NUMERIC ? CAP : 0);              // NUMERIC
+    uint32_t* ppos = (uint32_t*)(idx_b + (NUMERIC ? CAP : 0));  // NUMERIC: position of the product in B
+    uint16_t* pent = (uint16_t*)(ppos + (NUMERIC ? CAP : 0));   // NUMERIC: entry of the A row
+    uint16_t* cnt = pent + (NUMERIC ? CAP : 0);                 // [NW][256] digit counters, then offsets
+    int4* queue = (int4*)(cnt + NW * 256);                      // (offset, start in B, length, entry)
+    int32_t* tmp = (int32_t*)(queue + QCAP);                    // scan buffer NW + 1, queue length
+    int32_t* qlen = tmp + NW + 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row], lenA = a_ip[row + 1] - a0;
+
+    // A row with one entry is that row of B times a number: ascending columns already, and distinct ones
+    // unless the row of B repeats a column (rows of B may: the loader keeps duplicates).
+    if (lenA == 1) {
+        const int k = a_ix[a0];
+        const int b0 = b_ip[k], len = b_ip[k + 1] - b0;
+        int dup = 0;
+        for (int i = tid + 1; i < len; i += THREADS) dup |= b_ix[b0 + i] == b_ix[b0 + i - 1];
+        dup = __syncthreads_or(dup);
+        if (dup) goto general;
+        if (NUMERIC) {
+            const double a = a_val[a0];
+            const int64_t obase = c_ip[row] - c_ip[row_beg];
+            for (int i = tid; i < len; i += THREADS) {
+                c_ix[obase + i] = b_ix[b0 + i];
+                c_val[obase + i] = a * b_val[b0 + i];
+            }
+        } else if (tid == 0) {
+            rowcnt[row] = len;
+        }
+        return;
+    }
+general:
+
+    // ---- expand ------------------------------------------------------------------
+    int run = 0;
+    for (int e0 = 0; e0 < lenA; e0 += THREADS) {
+        const int e = e0 + tid;
+        int len = 0, b0 = 0;
+        if (e < lenA) {
+            const int k = a_ix[a0 + e];
+            b0 = b_ip[k];
+            len = b_ip[k + 1] - b0;
+        }
+        if (tid == 0) *qlen = 0;
+        int tot;
+        const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;   // barriers inside
+        if (len >= 64) {
+            queue[atomicAdd(qlen, 1)] = make_int4(off, b0, len, e);      // long runs: the whole workgroup copies them
+        } else {
+            for (int q = 0; q < len; q++) {
+                key_a[off + q] = (uint32_t)b_ix[b0 + q];
+                if (NUMERIC) { ppos[off + q] = (uint32_t)(b0 + q); pent[off + q] = (uint16_t)e; }
+            }
+        }
+        __syncthreads();
+        const int nq = *qlen;
+        for (int qi = 0; qi < nq; qi++) {
+            const int4 it = queue[qi];
+            for (int i = tid; i < it.z; i += THREADS) {
+                key_a[it.x + i] = (uint32_t)b_ix[it.y + i];
+                if (NUMERIC) { ppos[it.x + i] = (uint32_t)(it.y + i); pent[it.x + i] = (uint16_t)it.w; }
+            }
+        }
+        run += tot;
+        __syncthreads();
+    }
+    const int N = run;
+    if (NUMERIC)
+        for (int i = tid; i < N; i += THREADS) idx_a[i] = (uint16_t)i;
+    __syncthreads();
+
+    // ---- stable LSD radix sort of (key, idx) --------------------------------------
+    uint32_t* ks = key_a;
+    uint32_t* kd = key_b;
+    uint16_t* is = idx_a;
+    uint16_t* id = idx_b;
+    uint16_t* mycnt = cnt + wv * 256;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // Rows with at most ESC_MERGE_MAX entries (most of the rows sorted here) are that many ascending lists laid end
+    // to end: the place of a product in the merged order is its index in its own list plus, for every other
+    // list, the number of elements that go before it there (those not above it in an earlier list, those below
+    // it in a later one), i.e. up to three binary searches in LDS instead of three radix passes.
+    bool merged = false;
+    if (lenA <= ESC_MERGE_MAX) {
+        int o[ESC_MERGE_MAX + 1];
+        o[0] = 0;
+#pragma unroll
+        for (int e = 0; e < ESC_MERGE_MAX; e++) {
+            int len = 0;
+            if (e < lenA) {
+                const int k = a_ix[a0 + e];
+                len = b_ip[k + 1] - b_ip[k];
+            }
+            o[e + 1] = o[e] + len;
+        }
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int p = j * THREADS + tid;
+            if (p < N) {
+                const uint32_t x = key_a[p];
+                int l = 0, ol = 0;
+#pragma unroll
+                for (int q = 1; q < ESC_MERGE_MAX; q++)
+                    if (p >= o[q]) { l = q; ol = o[q]; }
+                int pos = p - ol;
+#pragma unroll
+                for (int q = 0; q < ESC_MERGE_MAX; q++) {
+                    if (q == l || q >= lenA) continue;
+                    int lo = o[q], hi = o[q + 1];
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const uint32_t y = key_a[mid];
+                        if (q < l ? y <= x : y < x) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    pos += lo - o[q];
+                }
+                key_b[pos] = x;
+                if (NUMERIC) idx_b[pos] = (uint16_t)p;
+            }
+        }
+        __syncthreads();
+        ks = key_b;
+        is = idx_b;
+        merged = true;
+    }
+    for (int shift = 0; shift < (merged ? 0 : key_bits); shift += 8) {
+        ((uint64_t*)mycnt)[lane] = 0ull;          // 256 counters of 16 bits per wave
+        wave_sync_lds();
+        uint32_t k[EPT];
+        int lrank[EPT];
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            if (wv * CPW + r * 64 >= N) break;    // wave-uniform: nothing of this round is in use
+            const int i = wv * CPW + r * 64 + lane;
+            const bool valid = i < N;
+            k[r] = valid ? ks[i] : 0xffffffffu;
+            const unsigned d = (k[r] >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            // the first lane of each group of equal digits advances the wave's counter
+            const int leader = valid ? __ffsll(peers) - 1 : lane;
+            int old = 0;
+            if (valid && lane == leader) {
+                old = mycnt[d];
+                mycnt[d] = (uint16_t)(old + __popcll(peers));
+            }
+            old = __shfl(old, leader, 64);
+            lrank[r] = old + __popcll(peers & lt_mask);
+            wave_sync_lds();
+        }
+        __syncthreads();
+        // exclusive scan over [digit][wave] in place: thread t owns 256*NW/THREADS consecutive cells
+        {
+            constexpr int CPT = 256 * NW / THREADS;
+            int v[CPT], sum = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int cell = tid * CPT + j;               // = digit * NW + wave
+                v[j] = cnt[(cell % NW) * 256 + cell / NW];
+                sum += v[j];
+            }
+            int tot;
+            int base = block_exclusive_scan_1b<THREADS, int32_t>(sum, tmp, &tot);   // a barrier inside: all reads done
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const int cell = tid * CPT + j;
+                cnt[(cell % NW) * 256 + cell / NW] = (uint16_t)base;
+                base += v[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EPT; r++) {
+            const int i = wv * CPW + r * 64 + lane;
+            if (i < N) {
+                const int dest = (int)mycnt[(k[r] >> shift) & 255u] + lrank[r];
+                kd[dest] = k[r];
+                if (NUMERIC) id[dest] = is[i];
+            }
+        }
+        __syncthreads();
+        uint32_t* tk = ks; ks = kd; kd = tk;
+        uint16_t* ti = is; is = id; id = ti;
+    }
+
+    // ---- compress: one output entry per run of equal columns -------------------------
+    int64_t obase = 0;
+    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
+    int heads = 0;
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+        const int i = tid * EPT + j;
+        heads += (i < N && (i == 0 || ks[i - 1] != ks[i])) ? 1 : 0;
+    }
+    int total;
+    int r = block_exclusive_scan<THREADS, int32_t>(heads, tmp, &total);
+    if (NUMERIC) {
+        // Every thread fetches the EPT products of its own sorted positions (independent gathers, all in
+        // flight together) and sums the runs that start in its range; what precedes its first run head
+        // continues a run of an earlier thread, which collects those leading sums through LDS.
+        double* lead = (double*)cnt;                   // THREADS sums; the digit counters are free now
+        uint8_t* has_head = (uint8_t*)(lead + THREADS);
+        static_assert((size_t)THREADS * 9 <= (size_t)NW * 512 + (size_t)QCAP * 16, "leading sums fit the counters and the queue");
+        double v[EPT];
+        uint32_t key[EPT];
+        bool hd[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int i = tid * EPT + j;
+            const int ic = i < N ? i : 0;
+            const int q = N > 0 ? is[ic] : 0;
+            key[j] = ks[ic];
+            hd[j] = i < N && (i == 0 || ks[ic - (i > 0 ? 1 : 0)] != key[j]);
+            v[j] = N > 0 ? a_val[a0 + pent[q]] * b_val[ppos[q]] : 0.0;
+        }
+        double lsum = 0.0, cur = 0.0;
+        uint32_t cur_key = 0;
+        bool open = false;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int i = tid * EPT + j;
+            if (i < N) {
+                if (hd[j]) {
+                    if (open) {
+                        c_ix[obase + r] = (int32_t)cur_key;
+                        c_val[obase + r] = cur;
+                        r++;
+                    }
+                    open = true;
+                    cur = v[j];
+                    cur_key = key[j];
+                } else if (open) {
+                    cur += v[j];
+                } else {
+                    lsum += v[j];
+                }
+            }
+        }
+        lead[tid] = lsum;
+        has_head[tid] = open ? 1 : 0;
+        __syncthreads();
+        if (open) {
+            // the thread's last run may go on in the ranges of the next threads
+            for (int t = tid + 1; t < THREADS && t * EPT < N; t++) {
+                cur += lead[t];
+                if (has_head[t]) break;
+            }
+            c_ix[obase + r] = (int32_t)cur_key;
+            c_val[obase + r] = cur;
+        }
+    } else if (tid == 0) {
+        rowcnt[row] = total;
+    }
+}
+
+template <int THREADS, int CAP, bool NUMERIC>
+constexpr size_t escr_lds_bytes() {
+    return (size_t)CAP * (NUMERIC ? 8 + 4 + 4 + 2 : 8) + (size_t)(THREADS / 64) * 512 + (size_t)(CAP / 64) * 16 +
+           (size_t)(THREADS / 64 + 2) * 4;
+}
+
+
+}  // namespace

@@ -1,0 +1,428 @@
+// Symbolic kernels of the product's window rows: k_symd (bitmap of 2^20 columns) and k_sym2 (hash set per window).
+// Part of the one translation unit spgemm.hip (included there, in this order: spgemm_common.h, spgemm_esc.h,
+// spgemm_win.h, spgemm_dense.h, spgemm_sym.h); gfx950 only.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Symbolic phase for window rows with the same barrier-free tiered sweep: the bitmap covers
+// SYM_COLS columns per pass (a whole row of C for matrices up to that width), a product costs one
+// 4-byte load and one ds_or_b32, and the row count is the popcount of the bitmap.
+#ifndef SYM_COLS_LOG2
+#define SYM_COLS_LOG2 20
+#endif
+constexpr int SYM_COLS = 1 << SYM_COLS_LOG2;
+
+// Column lc of the pass is bit lc / WORDS of word lc % WORDS: the consecutive columns that the lanes of a
+// wave mark when they walk one long segment of a row of B fall into consecutive words, i.e. distinct LDS
+// banks, instead of into the same word.
+__device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
+    const unsigned lc = (unsigned)(col - cbase);
+    atomicOr(&bits[lc & (SYM_COLS / 32 - 1)], 1u << (lc / (SYM_COLS / 32)));
+}
+
+#ifndef SYM_FEW
+#define SYM_FEW 64
+#endif
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                  const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
+                                                  const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                  int32_t* __restrict__ rowcnt, const int32_t* __restrict__ gslot,
+                                                  uint32_t* __restrict__ wcnt) {
+    constexpr int NW = THREADS / 64;
+    constexpr int WORDS = SYM_COLS / 32;
+    constexpr int WPT = WORDS / THREADS;
+    static_assert(WPT % 4 == 0, "the count pass reads 16 bytes at a time");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* bits = (uint32_t*)smem;
+    int32_t* tmp = (int32_t*)(bits + WORDS);
+    uint8_t* wmap = (uint8_t*)(tmp + 4) + (threadIdx.x >> 6) * 256;   // 256 bytes per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    const int lgE = lenA > 32 * NW ? 6 : lenA > 16 * NW ? 5 : 4;
+    const int E = 1 << lgE, LA = 64 >> lgE;
+    const int npass = (lenA + E * NW - 1) / (E * NW);
+    const int el = lane & (E - 1), pi = lane >> lgE;
+    const int mwin = SYM_COLS >> shift;   // table windows per bitmap pass
+    const int slot = gslot[row];          // >= 0: the numeric phase wants this row's entries per table window
+
+    for (int i = tid; i < WORDS / 4; i += THREADS) ((uint4*)bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) tmp[0] = 0;
+    // few entries: lane e of every wave keeps entry e's table row and the bounds of the current pass
+    static_assert(SYM_FEW <= 64, "one entry per lane");
+    const bool few = lenA <= SYM_FEW;
+    const int32_t* Tf = winptr;
+    int f_lo = 0, f_hi = 0;
+    if (few && lane < lenA) {
+        Tf = winptr + (int64_t)a_ix[a0 + lane] * tstride;
+        f_lo = Tf[0];
+        f_hi = Tf[mwin < nbase ? mwin : nbase];
+    }
+    __syncthreads();
+
+    for (int w0 = 0; w0 < nbase; w0 += mwin) {
+        const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
+        const int cbase = w0 << shift;
+        // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B): every wave
+        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
+        // the chunks dealt round the waves, eight per turn and wave, so that all waves carry the same
+        // load whatever the lengths of the segments.  The table bound of the next pass is loaded a pass
+        // ahead.
+        if (few) {
+            const int w2 = w1 + mwin < nbase ? w1 + mwin : nbase;
+            int f_nx = f_hi;
+            if (lane < lenA && w1 < nbase) f_nx = Tf[w2];
+            const int s = f_lo, len = f_hi - f_lo;
+            const int nch = (len + 63) >> 6;
+            const int inc = wave_inclusive_scan_i32(nch);
+            const int total = __builtin_amdgcn_readlane(inc, 63);
+            const int choff = inc - nch;
+            for (int j0 = wv; j0 < total; j0 += NW * 8) {
+                int cq[8];
+                bool ok[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int j = j0 + q * NW;
+                    const int jc = j < total ? j : total - 1;
+                    // the entry of chunk jc: the last one with chunks whose first chunk is not after jc
+                    const unsigned long long m = __ballot(nch > 0 && choff <= jc);
+                    const int e = 63 - __clzll((long long)m);
+                    const int se = __builtin_amdgcn_readlane(s, e), le = __builtin_amdgcn_readlane(len, e);
+                    const int i = (jc - __builtin_amdgcn_readlane(choff, e)) * 64 + lane;
+                    ok[q] = j < total && i < le;
+                    cq[q] = b_ix[se + (i < le ? i : le - 1)];   // unconditional load
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (ok[q]) sym_mark(bits, cq[q], cbase);
+            }
+            f_lo = f_hi;
+            f_hi = f_nx;
+        }
+        for (int c = 0; c < (few ? 0 : npass); c++) {
+            const int e = ((c << lgE) + el) * NW + wv;
+            int s = 0, len = 0;
+            if (e < lenA) {
+                const int32_t* Tq = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                s = Tq[w0];
+                len = Tq[w1] - s;
+            }
+            // tier 1: products pi and pi+LA of the lane's own entry (unconditional loads, position 0 when
+            // there is no such product); marked once the loads of tier 2's first batch are on their way
+            const bool v0 = pi < len, v1 = pi + LA < len;
+            const int q0 = b_ix[v0 ? s + pi : 0];
+            const int q1 = b_ix[v1 ? s + pi + LA : 0];
+            const int rem = lane < E ? len - 2 * LA : 0;
+            unsigned long long mask_c = __ballot(rem > 256);
+            // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
+            wave_flat_sweep<false>(b_ix, nullptr, s + 2 * LA, rem <= 256 ? rem : 0, 0.0, lane, wmap,
+                                   [&](int col, double, bool valid) { if (valid) sym_mark(bits, col, cbase); },
+                                   [&] {
+                                       if (v0) sym_mark(bits, q0, cbase);
+                                       if (v1) sym_mark(bits, q1, cbase);
+                                   });
+            // tier 3: the whole wave on one entry
+            while (mask_c) {
+                const int src = __ffsll(mask_c) - 1;
+                mask_c &= mask_c - 1;
+                const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
+                const int rr = __builtin_amdgcn_readlane(rem, src);
+                // 512 products per turn; the loads of the next turn are issued before the marks of this one
+                // (unconditional loads: lanes past the end repeat the last product and do not mark)
+                int cq[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * q;
+                    cq[q] = b_ix[ss + (i < rr ? i : rr - 1)];
+                }
+                for (int i0 = 0; i0 < rr; i0 += 512) {
+                    int nq[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int i = i0 + 512 + lane + 64 * q;
+                        nq[q] = b_ix[ss + (i < rr ? i : rr - 1)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (i0 + lane + 64 * q < rr) sym_mark(bits, cq[q], cbase);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) cq[q] = nq[q];
+                }
+            }
+        }
+        __syncthreads();
+        // count and clear: thread t owns words [WPT*t, WPT*(t+1))
+        if (slot >= 0) {
+            // entries of C per table window for the numeric phase: bit b of the thread's words covers columns
+            // b*WORDS + [WPT*t, WPT*(t+1)), which lie inside one table window for all threads of a wave
+            static_assert(WORDS % (64 * WPT) == 0 && (64 * WPT) <= (1 << WIN_SHIFT_MIN), "a wave's words stay inside a table window");
+            for (int b = 0; b < 32; b++) {
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < WPT / 4; j++) {
+                    const uint4 x = ((const uint4*)bits)[tid * (WPT / 4) + j];
+                    c += ((x.x >> b) & 1u) + ((x.y >> b) & 1u) + ((x.z >> b) & 1u) + ((x.w >> b) & 1u);
+                }
+                c = wave_reduce_sum(c);
+                const int w = w0 + (int)(((unsigned)b * WORDS + (unsigned)tid * WPT) >> shift);
+                if (lane == 0 && c) atomicAdd(&wcnt[(int64_t)slot * nbase + w], (uint32_t)c);
+            }
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < WPT / 4; j++) {
+            const uint4 x = ((const uint4*)bits)[tid * (WPT / 4) + j];
+            const int cj = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+            if (cj) ((uint4*)bits)[tid * (WPT / 4) + j] = make_uint4(0u, 0u, 0u, 0u);
+            cnt += cj;
+        }
+        cnt = wave_reduce_sum(cnt);
+        if (lane == 0 && cnt) atomicAdd(&tmp[0], cnt);
+        __syncthreads();
+    }
+    if (tid == 0) rowcnt[row] = tmp[0];
+}
+
+// ---------------------------------------------------------------------------
+// Symbolic phase of the light window rows: 256-thread workgroups of 28 KB, five per CU.  A row of few products in
+// a wide matrix costs k_symd a fixed price per 2^20 columns (a pass over all entries and a count over the 128 KB
+// bitmap); here a window is cut by its S2_CAP products, whatever its width: the products go to registers and their
+// columns into a hash set of S2_TAB slots (linear probing, compare-and-swap on LDS; the set is at most half
+// full), and the row's count is the number of insertions that found an empty slot.  No ranks are needed to count,
+// so a window has three barriers (two for the directory that maps a product to its place in B, one before the set
+// is cleared) where a bitmap with rank prefixes has six.  A window that the products of one table window overfill,
+// and every window of a row with more than 256 entries, uses the set's first S2_CAP words as a plain bitmap over at
+// most 2^16 columns and reads its products through the directory cursor instead.
+constexpr int S2_THREADS = 256, S2_U = 8, S2_CAP = S2_U * S2_THREADS, S2_TAB = 2 * S2_CAP, S2_TAB_LOG2 = 12;
+static_assert(S2_TAB == 1 << S2_TAB_LOG2, "the hash takes the top bits of a 32-bit product");
+__global__ void __launch_bounds__(S2_THREADS, 5) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                        const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
+                                                        const int32_t* __restrict__ winptr, int nbase, int shift,
+                                                        int32_t* __restrict__ rowcnt) {
+    constexpr int THREADS = S2_THREADS, NW = THREADS / 64, U = S2_U;
+    static_assert(U == 8, "eight 16-bit marks per thread move as one 16-byte piece");
+    __shared__ __align__(16) uint32_t tab[S2_TAB];   // hash set of (column - first column of the window + 1), 0 = empty
+    uint32_t* const fine = tab;                       // plain bitmap of the windows that do not take the set
+    __shared__ __align__(16) uint16_t emap[S2_CAP];
+    __shared__ int2 dirs[2][THREADS + 1];
+    __shared__ uint32_t cs[1026];
+    __shared__ int32_t tmp_a[NW + 1], tmp_c[NW + 1], wave_ent[NW], total_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = list[blockIdx.x];
+    const int a0 = a_ip[row];
+    const int lenA = a_ip[row + 1] - a0;
+    const int64_t tstride = (int64_t)nbase + 1;
+    const bool single = lenA <= THREADS;
+    for (int i = tid; i < S2_TAB; i += THREADS) tab[i] = 0u;
+    if (tid == 0) total_cnt = 0;
+    // cs[j] = sum over the row's entries of the table value at window j: the products of a range of table windows
+    // are a difference of two of them
+    for (int j = tid; j <= nbase; j += THREADS) cs[j] = 0u;
+    __syncthreads();
+    {
+        // (entry, table window) pairs dealt to the waves 64 windows of one entry at a time, eight loads in flight per lane
+        constexpr int CSU = 8;
+        const int gw = (nbase + 64) & ~63;   // window slots per entry (0 .. nbase, padded to whole waves)
+        const int npairs = lenA * gw;
+        for (int p0 = wv * 64; p0 < npairs; p0 += THREADS * CSU) {
+            uint32_t v[CSU];
+            int jj[CSU];
+#pragma unroll
+            for (int q = 0; q < CSU; q++) {
+                const int p = p0 + q * THREADS;   // wave-uniform
+                const int e = p / gw;
+                const int j = p - e * gw + lane;
+                const bool ok = p < npairs && j <= nbase;
+                v[q] = ok ? (uint32_t)winptr[(int64_t)a_ix[a0 + e] * tstride + j] : 0u;
+                jj[q] = j;
+            }
+#pragma unroll
+            for (int q = 0; q < CSU; q++)
+                if (v[q]) atomicAdd(&cs[jj[q]], v[q]);
+        }
+    }
+    __syncthreads();
+    // widest window in table windows: what the search below covers for the hash set of a single-chunk row, what the
+    // plain bitmap covers otherwise
+    const int gmax = single ? 256 : ((S2_CAP * 32) >> shift);
+    auto window_end = [&](int w0) {
+        // a window of k table windows fits (monotone in k): lanes try 4, 8, .. 256, then three lanes the ones between
+        const uint32_t base = cs[w0];
+        auto fit = [&](int k) {
+            const int jk = w0 + k < nbase ? w0 + k : nbase;
+            return k <= gmax && w0 + k <= nbase && cs[jk] - base <= (uint32_t)S2_CAP;
+        };
+        const unsigned long long m1 = __ballot(fit(4 * (lane + 1)));
+        const int c1 = m1 == ~0ull ? 64 : __ffsll(~m1) - 1;
+        const unsigned long long m2 = __ballot(lane < 3 && fit(4 * c1 + 1 + lane));
+        const int c2 = __ffsll(~m2) - 1;
+        const int k = 4 * c1 + c2 > 1 ? 4 * c1 + c2 : 1;
+        return w0 + k < nbase ? w0 + k : nbase;
+    };
+    int w1_cur = window_end(0), w1_next = 0;
+    const int32_t* T = winptr;
+    int t_lo = 0, t_hi = 0;
+    if (single && tid < lenA) {
+        T = winptr + (int64_t)a_ix[a0 + tid] * tstride;
+        t_lo = T[0];
+        t_hi = T[w1_cur];
+    }
+    int mycount = 0, flip = 0;
+    for (int w0 = 0; w0 < nbase; w0 = w1_cur, w1_cur = w1_next) {
+        const int w1 = w1_cur;
+        w1_next = w1 < nbase ? window_end(w1) : nbase;
+        const uint32_t prod_w = cs[w1] - cs[w0];
+        // this entry's part of the window (single-chunk rows); the bound of the next window is loaded a window ahead
+        int s = 0, len = 0;
+        if (single && tid < lenA) {
+            s = t_lo;
+            len = t_hi - t_lo;
+            t_lo = t_hi;
+            if (w1 < nbase) t_hi = T[w1_next];
+        }
+        if (prod_w == 0u) continue;   // block-uniform
+        const int wbase = w0 << shift;
+        if (single && prod_w <= (uint32_t)S2_CAP) {
+            // ---- hash set of the window's columns, products in registers ---------------------------------------
+            // the directory alternates between two buffers, so its build needs no barrier in front
+            flip ^= 1;
+            int2* dir = dirs[flip];
+            ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < NW) wave_ent[tid] = 0;
+            int Tc;
+            const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
+            dir[tid] = make_int2(off, s);
+            if (len > 0) {
+                // where this entry's products start, and the 512-product slices that start inside it
+                emap[off] = (uint16_t)(tid + 1);
+                for (int b = off / (U * 64) + 1; b * (U * 64) < off + len; b++) wave_ent[b] = tid + 1;
+            }
+            __syncthreads();
+            const int p_lo = wv * (U * 64);
+            const int p_hi = p_lo + U * 64 < Tc ? p_lo + U * 64 : Tc;
+            if (p_lo < p_hi) {   // wave-uniform
+                // running maximum of the marks over the slice = entry (+1) of every product
+                uint4* mine = (uint4*)(emap + p_lo + lane * U);
+                const uint4 raw = *mine;
+                int v[U] = {(int)(raw.x & 0xffffu), (int)(raw.x >> 16), (int)(raw.y & 0xffffu), (int)(raw.y >> 16),
+                            (int)(raw.z & 0xffffu), (int)(raw.z >> 16), (int)(raw.w & 0xffffu), (int)(raw.w >> 16)};
+#pragma unroll
+                for (int i = 1; i < U; i++) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
+                const int inc = wave_inclusive_max_nonneg(v[U - 1]);
+                int before = dpp_shr1(inc);
+                const int wb = wave_ent[wv];
+                before = (lane != 0 && before > wb) ? before : wb;
+#pragma unroll
+                for (int i = 0; i < U; i++) v[i] = v[i] > before ? v[i] : before;
+                *mine = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                                   (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+                wave_sync_lds();   // the other lanes of the wave read these entries next
+                int pos[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int p = p_lo + j * 64 + lane;
+                    const int pc = p < p_hi ? p : p_hi - 1;   // lanes past the end repeat the slice's last product: found in the set
+                    const int2 d = dir[(int)emap[pc] - 1];
+                    pos[j] = d.y + (pc - d.x);
+                }
+                uint32_t key[U], h[U], old[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) key[j] = (uint32_t)(b_ix[pos[j]] - wbase) + 1u;
+                // the first probes of all eight keys go out together; a key that meets another one walks on alone
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    h[j] = (key[j] * 0x9E3779B1u) >> (32 - S2_TAB_LOG2);
+                    old[j] = atomicCAS(&tab[h[j]], 0u, key[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    uint32_t o = old[j], hh = h[j];
+                    while (o != 0u && o != key[j]) {   // ends: the set holds at most S2_CAP of its S2_TAB slots
+                        hh = (hh + 1u) & (uint32_t)(S2_TAB - 1);
+                        o = atomicCAS(&tab[hh], 0u, key[j]);
+                    }
+                    mycount += o == 0u;
+                }
+            }
+            __syncthreads();
+            // clear the set: the next window's first insertions follow the two barriers of its directory build
+            static_assert(S2_TAB == 16 * THREADS, "four 16-byte stores per thread");
+#pragma unroll
+            for (int j = 0; j < 4; j++) ((uint4*)tab)[j * THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            // ---- plain bitmap of the window in `fine`, products through the directory cursor --------------------
+            int2* dir = dirs[0];
+            for (int c0 = 0; c0 < lenA; c0 += THREADS) {
+                __syncthreads();   // earlier readers of the directory, and the clearing of the window before
+                if (!single) {
+                    const int e = c0 + tid;
+                    s = 0;
+                    len = 0;
+                    if (e < lenA) {
+                        const int32_t* Tp = winptr + (int64_t)a_ix[a0 + e] * tstride;
+                        s = Tp[w0];
+                        len = Tp[w1] - s;
+                    }
+                }
+                int Tc;
+                const int off = block_exclusive_scan<THREADS, int32_t>(len, tmp_c, &Tc);
+                dir[tid] = make_int2(off, s);
+                if (tid == 0) dir[THREADS] = make_int2(Tc, 0);
+                __syncthreads();
+                if (Tc == 0) continue;
+                const int per = ((Tc + NW - 1) / NW + 63) & ~63;
+                const int p_lo = wv * per;
+                const int p_hi = p_lo + per < Tc ? p_lo + per : Tc;
+                if (p_lo >= p_hi) continue;   // wave-uniform
+                WinCursor<THREADS> cur;
+                cur.init(dir, p_lo + lane < p_hi ? p_lo + lane : p_hi - 1);
+                for (int pb = p_lo; pb < p_hi; pb += 64 * 4) {
+                    int pos[4];
+                    unsigned ok = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int p = pb + j * 64 + lane;
+                        pos[j] = 0;
+                        if (p < p_hi) {
+                            ok |= 1u << j;
+                            cur.seek(dir, p);
+                            pos[j] = cur.start + (p - cur.off);
+                        }
+                    }
+                    int c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) c[j] = b_ix[pos[j]];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (ok & (1u << j)) atomicOr(&fine[(c[j] - wbase) >> 5], 1u << ((c[j] - wbase) & 31));
+                }
+            }
+            __syncthreads();
+            {
+                const uint4 fa = ((const uint4*)fine)[2 * tid], fb = ((const uint4*)fine)[2 * tid + 1];
+                const int c = __popc(fa.x) + __popc(fa.y) + __popc(fa.z) + __popc(fa.w) + __popc(fb.x) + __popc(fb.y) +
+                              __popc(fb.z) + __popc(fb.w);
+                if (c) {
+                    ((uint4*)fine)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+                    ((uint4*)fine)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                mycount += c;
+            }
+        }
+    }
+    mycount = wave_reduce_sum(mycount);
+    if (lane == 0 && mycount) atomicAdd(&total_cnt, mycount);
+    __syncthreads();
+    if (tid == 0) rowcnt[row] = total_cnt;
+}
+
+constexpr size_t symd_lds_bytes() { return (size_t)SYM_COLS / 8 + 16 + 16 * 256; }
+
+}  // namespace

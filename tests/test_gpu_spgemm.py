@@ -374,13 +374,17 @@ def test_repeated_steps_keep_the_plan_and_stay_exact(ctx):
     counts again; then the other matrix of the same shape in between (a miss), and the first once more."""
     n, mats, outs = _same_shape_pair()
     A = [capi.Csr(n, n, *m) for m in mats]
-    for k in (0, 0, 1, 0, 0):
+    for step, k in enumerate((0, 0, 1, 0, 0, 0)):
+        if step == 5:
+            ctx.forget_plan()          # the last step rebuilds everything although the matrices are the same
         c_ip, nnz_c, _ = ctx.spgemm_symbolic(A[k])
         assert np.array_equal(c_ip, outs[k][0]) and nnz_c == int(outs[k][0][-1])
         mid = n // 2
         for r0, r1 in ((0, mid), (mid, n)):
             ci, cd = ctx.spgemm_numeric(A[k], None, c_ip, r0, r1)
             assert np.array_equal(ci, outs[k][1][c_ip[r0]:c_ip[r1]]) and np.array_equal(cd, outs[k][2][c_ip[r0]:c_ip[r1]])
+            if step == 5 and r0 == 0:
+                ctx.forget_plan()      # and between the numeric calls of one product
 
 
 def test_plan_of_another_matrix_is_not_reused_dev_refill(ctx):

@@ -2,7 +2,9 @@
 """How evenly does bench.py's row partition spread the work?  One GPU runs the row shard of every rank of
 an N-rank job in turn (symbolic + numeric, the same calls as bench.py's step) and reports the time of
 each; the N-rank step time is the largest of them (the ranks exchange nothing during a step).
-usage: shard_balance.py <scale> <world> [steps]"""
+usage: shard_balance.py <scale | askubuntu | stanford> <world> [steps] [seed]
+(a scale is an R-MAT graph of edge factor 16; seed 7 is the one the cost model was fitted on, any other is held out;
+the two names are the SNAP-sized stand-ins of spmm_amd.synth)"""
 import json
 import os
 import sys
@@ -17,13 +19,22 @@ from spmm_amd import capi, shard  # noqa: E402
 
 
 def main():
-    scale, world = int(sys.argv[1]), int(sys.argv[2])
+    graph, world = sys.argv[1], int(sys.argv[2])
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 7
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    n = 1 << scale
-    row, col = rmat_torch(scale, 16, 7, dev)
+    if graph in ("askubuntu", "stanford"):
+        from spmm_amd import synth
+        n, gen = (159316, synth.askubuntu_like) if graph == "askubuntu" else (281903, synth.stanford_like)
+        r_h, c_h = gen()
+        row, col = torch.from_numpy(r_h).to(dev), torch.from_numpy(c_h).to(dev)
+        scale = graph
+    else:
+        scale = int(graph)
+        n = 1 << scale
+        row, col = rmat_torch(scale, 16, seed, dev)
     nnz = int(row.numel())
     indptr, indices, data = build_csr(ctx, n, n, row, col)
     del row, col
@@ -64,7 +75,7 @@ def main():
         out.append(dict(rank=r, rows=rows_l, products=int(pl.sum()), ms=round(ms, 2),
                         dense_products=int(pl[pl >= dense_min].sum()), sorted_products=int(pl[pl <= esc_max].sum())))
     mx, mean = max(o["ms"] for o in out), sum(o["ms"] for o in out) / world
-    print(json.dumps(dict(scale=scale, world=world, ranks=out, max_ms=mx, mean_ms=round(mean, 2),
+    print(json.dumps(dict(scale=scale, seed=seed, world=world, ranks=out, max_ms=mx, mean_ms=round(mean, 2),
                           balance=round(mean / mx, 3), projected_gflops=round(2.0 * P_total / (mx * 1e-3) / 1e9, 1))))
 
 
