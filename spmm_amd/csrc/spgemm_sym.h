@@ -23,8 +23,97 @@ __device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
     atomicOr(&bits[lc & (SYM_COLS / 32 - 1)], 1u << (lc / (SYM_COLS / 32)));
 }
 
+// Four consecutive column ids of a segment of a row of B with one 16-byte load (the address is only 4-byte aligned: the
+// hardware takes that).  A lane wants the products [want, want + 4) of the segment that ends at seg_end; near the end
+// the load moves back so that it stays inside the segment (inside the array when the segment is shorter than four),
+// and sym_mark4 skips what lies in front of `want` or behind the end.  A quarter of the load instructions and of the
+// address arithmetic of one product per lane and load.
+struct seg4 { int4 v; int first; };
+__device__ __forceinline__ seg4 ld_seg4(const int32_t* __restrict__ b_ix, int want, int seg_end) {
+    int idx = want < seg_end - 4 ? want : seg_end - 4;
+    idx = idx > 0 ? idx : 0;
+    seg4 r;
+    r.v = *reinterpret_cast<const int4*>(b_ix + idx);
+    r.first = idx;
+    return r;
+}
+__device__ __forceinline__ void sym_mark4(uint32_t* bits, const seg4& x, int want, int seg_end, int cbase) {
+    const int lo = want - x.first, hi = seg_end - x.first;   // elements lo .. hi-1 are the lane's own
+    if (0 >= lo && 0 < hi) sym_mark(bits, x.v.x, cbase);
+    if (1 >= lo && 1 < hi) sym_mark(bits, x.v.y, cbase);
+    if (2 >= lo && 2 < hi) sym_mark(bits, x.v.z, cbase);
+    if (3 >= lo && 3 < hi) sym_mark(bits, x.v.w, cbase);
+}
+
+// The flattened wave-level sweep (wave_flat_sweep) in packs of four consecutive products: lanes hold (s, rem) = start and
+// count of what is left of their entry's segment, an entry has (rem + 3) / 4 packs, the packs of all entries form one
+// index space, a batch is 256 of them (1024 products), four per lane, all loaded before any is marked.  between() is
+// called once, after the loads of the first batch have been issued (or at the end when there is no batch).
+template <typename G>
+__device__ __forceinline__ void wave_flat_sweep_sym4(const int32_t* __restrict__ b_ix, int s, int rem, int lane, uint8_t* wmap,
+                                                     uint32_t* bits, int cbase, G&& between) {
+    uint32_t* wmap4 = (uint32_t*)wmap;
+    rem = rem > 0 ? rem : 0;
+    const int np = (rem + 3) >> 2;
+    int inc = np;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        inc += lane >= d ? o : 0;
+    }
+    const int R = __builtin_amdgcn_readlane(inc, 63);
+    const int o = inc - np;          // index of the entry's first pack
+    const int so = s - 4 * o;        // pack q of this entry starts at so + 4 q
+    const int send = s + rem;
+    for (int b0 = 0; b0 < R; b0 += 256) {
+        wmap4[lane] = 0u;
+        if (np > 0 && o >= b0 && o < b0 + 256) wmap[o - b0] = (uint8_t)(lane + 1);
+        const unsigned long long hold = __ballot(np > 0 && o < b0 && o + np > b0);
+        const int base = hold ? __ffsll(hold) : 0;
+        wave_sync_lds();   // the marks of the other lanes
+        const uint32_t raw = wmap4[lane];
+        int v0 = (int)(raw & 0xffu), v1 = (int)((raw >> 8) & 0xffu), v2 = (int)((raw >> 16) & 0xffu), v3 = (int)(raw >> 24);
+        v1 = v1 > v0 ? v1 : v0;
+        v2 = v2 > v1 ? v2 : v1;
+        v3 = v3 > v2 ? v3 : v2;
+        int run = v3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int x = __shfl_up(run, d, 64);
+            run = (lane >= d && x > run) ? x : run;
+        }
+        int before = __shfl_up(run, 1, 64);
+        before = (lane != 0 && before > base) ? before : base;
+        v0 = v0 > before ? v0 : before;
+        v1 = v1 > before ? v1 : before;
+        v2 = v2 > before ? v2 : before;
+        v3 = v3 > before ? v3 : before;
+        wmap4[lane] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+        wave_sync_lds();   // the filled map of the other lanes
+        seg4 cq[4];
+        int want[4], se[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int q = b0 + j * 64 + lane;
+            const int qc = q < R ? q : R - 1;                 // lanes past the end repeat the last pack and mark nothing
+            const int src = (int)wmap[qc - b0] - 1;
+            want[j] = __shfl(so, src, 64) + 4 * qc;
+            const int e_ = __shfl(send, src, 64);
+            cq[j] = ld_seg4(b_ix, want[j], e_);
+            se[j] = q < R ? e_ : 0;
+        }
+        if (b0 == 0) between();
+#pragma unroll
+        for (int j = 0; j < 4; j++) sym_mark4(bits, cq[j], want[j], se[j], cbase);
+    }
+    if (R <= 0) between();
+}
+
 #ifndef SYM_FEW
 #define SYM_FEW 64
+#endif
+#ifndef SYM_T2MAX
+#define SYM_T2MAX 512     // entries with more products left after tier 1 take the whole wave
 #endif
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
@@ -71,37 +160,37 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
         const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
         const int cbase = w0 << shift;
         // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B): every wave
-        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 64 products and
-        // the chunks dealt round the waves, eight per turn and wave, so that all waves carry the same
-        // load whatever the lengths of the segments.  The table bound of the next pass is loaded a pass
+        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 256 products (four
+        // consecutive ones per lane: ld_seg4) and the chunks dealt round the waves, four per turn and wave, so
+        // that all waves carry the same load whatever the lengths of the segments.  The table bound of the next pass is loaded a pass
         // ahead.
         if (few) {
             const int w2 = w1 + mwin < nbase ? w1 + mwin : nbase;
             int f_nx = f_hi;
             if (lane < lenA && w1 < nbase) f_nx = Tf[w2];
             const int s = f_lo, len = f_hi - f_lo;
-            const int nch = (len + 63) >> 6;
+            const int nch = (len + 255) >> 8;   // chunks of 256 products: four per lane
             const int inc = wave_inclusive_scan_i32(nch);
             const int total = __builtin_amdgcn_readlane(inc, 63);
             const int choff = inc - nch;
-            for (int j0 = wv; j0 < total; j0 += NW * 8) {
-                int cq[8];
-                bool ok[8];
+            constexpr int SQ = 4;   // chunks per turn and wave
+            for (int j0 = wv; j0 < total; j0 += NW * SQ) {
+                seg4 cq[SQ];
+                int want[SQ], send[SQ];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
+                for (int q = 0; q < SQ; q++) {
                     const int j = j0 + q * NW;
                     const int jc = j < total ? j : total - 1;
                     // the entry of chunk jc: the last one with chunks whose first chunk is not after jc
                     const unsigned long long m = __ballot(nch > 0 && choff <= jc);
                     const int e = 63 - __clzll((long long)m);
                     const int se = __builtin_amdgcn_readlane(s, e), le = __builtin_amdgcn_readlane(len, e);
-                    const int i = (jc - __builtin_amdgcn_readlane(choff, e)) * 64 + lane;
-                    ok[q] = j < total && i < le;
-                    cq[q] = b_ix[se + (i < le ? i : le - 1)];   // unconditional load
+                    send[q] = j < total ? se + le : 0;   // a chunk past the end marks nothing
+                    want[q] = se + (jc - __builtin_amdgcn_readlane(choff, e)) * 256 + 4 * lane;
+                    cq[q] = ld_seg4(b_ix, want[q], se + le);   // unconditional load
                 }
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (ok[q]) sym_mark(bits, cq[q], cbase);
+                for (int q = 0; q < SQ; q++) sym_mark4(bits, cq[q], want[q], send[q], cbase);
             }
             f_lo = f_hi;
             f_hi = f_nx;
@@ -114,46 +203,35 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
                 s = Tq[w0];
                 len = Tq[w1] - s;
             }
-            // tier 1: products pi and pi+LA of the lane's own entry (unconditional loads, position 0 when
-            // there is no such product); marked once the loads of tier 2's first batch are on their way
-            const bool v0 = pi < len, v1 = pi + LA < len;
-            const int q0 = b_ix[v0 ? s + pi : 0];
-            const int q1 = b_ix[v1 ? s + pi + LA : 0];
-            const int rem = lane < E ? len - 2 * LA : 0;
-            unsigned long long mask_c = __ballot(rem > 256);
-            // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
-            wave_flat_sweep<false>(b_ix, nullptr, s + 2 * LA, rem <= 256 ? rem : 0, 0.0, lane, wmap,
-                                   [&](int col, double, bool valid) { if (valid) sym_mark(bits, col, cbase); },
-                                   [&] {
-                                       if (v0) sym_mark(bits, q0, cbase);
-                                       if (v1) sym_mark(bits, q1, cbase);
-                                   });
+            // tier 1: the first 4*LA products of every entry by the entry's own lanes, four consecutive ones per lane
+            // (unconditional load); marked once the loads of tier 2's first batch are on their way
+            const int want1 = s + 4 * pi;
+            const seg4 t1 = ld_seg4(b_ix, want1, s + len);
+            const int rem = lane < E ? len - 4 * LA : 0;
+            unsigned long long mask_c = __ballot(rem > SYM_T2MAX);
+            // tier 2: the rest of all entries with up to SYM_T2MAX more products, flattened over the wave in packs of four
+            wave_flat_sweep_sym4(b_ix, s + 4 * LA, rem <= SYM_T2MAX ? rem : 0, lane, wmap, bits, cbase,
+                                 [&] { sym_mark4(bits, t1, want1, s + len, cbase); });
             // tier 3: the whole wave on one entry
             while (mask_c) {
                 const int src = __ffsll(mask_c) - 1;
                 mask_c &= mask_c - 1;
-                const int ss = __builtin_amdgcn_readlane(s, src) + 2 * LA;
+                const int ss = __builtin_amdgcn_readlane(s, src) + 4 * LA;
                 const int rr = __builtin_amdgcn_readlane(rem, src);
-                // 512 products per turn; the loads of the next turn are issued before the marks of this one
-                // (unconditional loads: lanes past the end repeat the last product and do not mark)
-                int cq[8];
+                // 512 products per turn, four consecutive ones per lane and load; the loads of the next turn are issued
+                // before the marks of this one (unconditional loads: see ld_seg4)
+                const int send = ss + rr;
+                seg4 cq[2];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int i = lane + 64 * q;
-                    cq[q] = b_ix[ss + (i < rr ? i : rr - 1)];
-                }
+                for (int q = 0; q < 2; q++) cq[q] = ld_seg4(b_ix, ss + 256 * q + 4 * lane, send);
                 for (int i0 = 0; i0 < rr; i0 += 512) {
-                    int nq[8];
+                    seg4 nq[2];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int i = i0 + 512 + lane + 64 * q;
-                        nq[q] = b_ix[ss + (i < rr ? i : rr - 1)];
-                    }
+                    for (int q = 0; q < 2; q++) nq[q] = ld_seg4(b_ix, ss + i0 + 512 + 256 * q + 4 * lane, send);
 #pragma unroll
-                    for (int q = 0; q < 8; q++)
-                        if (i0 + lane + 64 * q < rr) sym_mark(bits, cq[q], cbase);
+                    for (int q = 0; q < 2; q++) sym_mark4(bits, cq[q], ss + i0 + 256 * q + 4 * lane, send, cbase);
 #pragma unroll
-                    for (int q = 0; q < 8; q++) cq[q] = nq[q];
+                    for (int q = 0; q < 2; q++) cq[q] = nq[q];
                 }
             }
         }

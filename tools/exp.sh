@@ -1,1 +1,6 @@
-tools/runvar.sh do1 22 && tools/runvar.sh do7k 22 SPMM_WIN_DENSE_OVER=7168 && tools/runvar.sh do6k 22 SPMM_WIN_DENSE_OVER=6144 && tools/runvar.sh do5k 22 SPMM_WIN_DENSE_OVER=5120 && tools/runvar.sh do4k 22 SPMM_WIN_DENSE_OVER=4096
+#!/bin/bash
+# scratch: variants of the current build
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout -k 10 900 python -u -m pytest tests/test_gpu_spgemm.py -x -q --timeout 300 --timeout-method thread -k "default or cursor or dense_all" > gpurun_out/exp_tests.log 2>&1 || { tail -15 gpurun_out/exp_tests.log; exit 1; }
+tail -2 gpurun_out/exp_tests.log
+bash tools/runvar.sh sy3 22 SPMM_NOP=1 || exit 1
