@@ -18,9 +18,11 @@ constexpr int SYM_COLS = 1 << SYM_COLS_LOG2;
 // Column lc of the pass is bit lc / WORDS of word lc % WORDS: the consecutive columns that the lanes of a
 // wave mark when they walk one long segment of a row of B fall into consecutive words, i.e. distinct LDS
 // banks, instead of into the same word.
+// (A pass starts at a multiple of SYM_COLS columns, so the word needs no subtraction of the pass's first column.)
 __device__ __forceinline__ void sym_mark(uint32_t* bits, int col, int cbase) {
-    const unsigned lc = (unsigned)(col - cbase);
-    atomicOr(&bits[lc & (SYM_COLS / 32 - 1)], 1u << (lc / (SYM_COLS / 32)));
+    (void)cbase;
+    const unsigned c = (unsigned)col;
+    atomicOr(&bits[c & (SYM_COLS / 32 - 1)], 1u << ((c / (SYM_COLS / 32)) & 31u));
 }
 
 // Four consecutive column ids of a segment of a row of B with one 16-byte load (the address is only 4-byte aligned: the
@@ -39,10 +41,17 @@ __device__ __forceinline__ seg4 ld_seg4(const int32_t* __restrict__ b_ix, int wa
 }
 __device__ __forceinline__ void sym_mark4(uint32_t* bits, const seg4& x, int want, int seg_end, int cbase) {
     const int lo = want - x.first, hi = seg_end - x.first;   // elements lo .. hi-1 are the lane's own
-    if (0 >= lo && 0 < hi) sym_mark(bits, x.v.x, cbase);
-    if (1 >= lo && 1 < hi) sym_mark(bits, x.v.y, cbase);
-    if (2 >= lo && 2 < hi) sym_mark(bits, x.v.z, cbase);
-    if (3 >= lo && 3 < hi) sym_mark(bits, x.v.w, cbase);
+    if (__all(lo <= 0 && hi >= 4)) {   // whole packs in every lane (all but the packs at the segments' ends)
+        sym_mark(bits, x.v.x, cbase);
+        sym_mark(bits, x.v.y, cbase);
+        sym_mark(bits, x.v.z, cbase);
+        sym_mark(bits, x.v.w, cbase);
+    } else {
+        if (0 >= lo && 0 < hi) sym_mark(bits, x.v.x, cbase);
+        if (1 >= lo && 1 < hi) sym_mark(bits, x.v.y, cbase);
+        if (2 >= lo && 2 < hi) sym_mark(bits, x.v.z, cbase);
+        if (3 >= lo && 3 < hi) sym_mark(bits, x.v.w, cbase);
+    }
 }
 
 // The flattened wave-level sweep (wave_flat_sweep) in packs of four consecutive products: lanes hold (s, rem) = start and
@@ -110,7 +119,7 @@ __device__ __forceinline__ void wave_flat_sweep_sym4(const int32_t* __restrict__
 }
 
 #ifndef SYM_FEW
-#define SYM_FEW 64
+#define SYM_FEW 256   // measured at R-MAT-22: 64 / 128 / 256 / 512 entries: 173 / 175 / 169 / 169 ms of symbolic window rows
 #endif
 #ifndef SYM_T2MAX
 #define SYM_T2MAX 512     // entries with more products left after tier 1 take the whole wave
@@ -144,56 +153,67 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 
     for (int i = tid; i < WORDS / 4; i += THREADS) ((uint4*)bits)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) tmp[0] = 0;
-    // few entries: lane e of every wave keeps entry e's table row and the bounds of the current pass
-    static_assert(SYM_FEW <= 64, "one entry per lane");
+    // few entries: lane l of every wave keeps the entries l, 64 + l, ... : their rows of B and the bounds of the current pass
+    static_assert(SYM_FEW % 64 == 0 && SYM_FEW >= 64 && SYM_FEW <= 512, "whole groups of one entry per lane");
+    constexpr int FG = SYM_FEW / 64;
     const bool few = lenA <= SYM_FEW;
-    const int32_t* Tf = winptr;
-    int f_lo = 0, f_hi = 0;
-    if (few && lane < lenA) {
-        Tf = winptr + (int64_t)a_ix[a0 + lane] * tstride;
-        f_lo = Tf[0];
-        f_hi = Tf[mwin < nbase ? mwin : nbase];
+    int f_k[FG], f_lo[FG], f_hi[FG];
+#pragma unroll
+    for (int g = 0; g < FG; g++) {
+        f_k[g] = 0; f_lo[g] = 0; f_hi[g] = 0;
+        if (few && g * 64 + lane < lenA) {
+            f_k[g] = a_ix[a0 + g * 64 + lane];
+            const int32_t* Tf = winptr + (int64_t)f_k[g] * tstride;
+            f_lo[g] = Tf[0];
+            f_hi[g] = Tf[mwin < nbase ? mwin : nbase];
+        }
     }
     __syncthreads();
 
     for (int w0 = 0; w0 < nbase; w0 += mwin) {
         const int w1 = w0 + mwin < nbase ? w0 + mwin : nbase;
         const int cbase = w0 << shift;
-        // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B): every wave
-        // holds entry `lane`'s segment of the pass, the segments are cut into chunks of 256 products (four
+        // Rows with at most SYM_FEW entries (most rows: a few entries that name long rows of B), 64 entries at a time:
+        // every wave holds entry `lane`'s segment of the pass, the segments are cut into chunks of 256 products (four
         // consecutive ones per lane: ld_seg4) and the chunks dealt round the waves, four per turn and wave, so
-        // that all waves carry the same load whatever the lengths of the segments.  The table bound of the next pass is loaded a pass
-        // ahead.
+        // that all waves carry the same load whatever the lengths of the segments.  The table bound of the next pass
+        // is loaded a pass ahead.
         if (few) {
             const int w2 = w1 + mwin < nbase ? w1 + mwin : nbase;
-            int f_nx = f_hi;
-            if (lane < lenA && w1 < nbase) f_nx = Tf[w2];
-            const int s = f_lo, len = f_hi - f_lo;
-            const int nch = (len + 255) >> 8;   // chunks of 256 products: four per lane
-            const int inc = wave_inclusive_scan_i32(nch);
-            const int total = __builtin_amdgcn_readlane(inc, 63);
-            const int choff = inc - nch;
-            constexpr int SQ = 4;   // chunks per turn and wave
-            for (int j0 = wv; j0 < total; j0 += NW * SQ) {
-                seg4 cq[SQ];
-                int want[SQ], send[SQ];
+            int dealt = 0;   // chunks of the groups before: the next group starts with the wave after the last one served
 #pragma unroll
-                for (int q = 0; q < SQ; q++) {
-                    const int j = j0 + q * NW;
-                    const int jc = j < total ? j : total - 1;
-                    // the entry of chunk jc: the last one with chunks whose first chunk is not after jc
-                    const unsigned long long m = __ballot(nch > 0 && choff <= jc);
-                    const int e = 63 - __clzll((long long)m);
-                    const int se = __builtin_amdgcn_readlane(s, e), le = __builtin_amdgcn_readlane(len, e);
-                    send[q] = j < total ? se + le : 0;   // a chunk past the end marks nothing
-                    want[q] = se + (jc - __builtin_amdgcn_readlane(choff, e)) * 256 + 4 * lane;
-                    cq[q] = ld_seg4(b_ix, want[q], se + le);   // unconditional load
+            for (int g = 0; g < FG; g++) {
+                if (g * 64 >= lenA) break;   // block-uniform
+                int f_nx = f_hi[g];
+                if (g * 64 + lane < lenA && w1 < nbase) f_nx = winptr[(int64_t)f_k[g] * tstride + w2];
+                const int s = f_lo[g], len = f_hi[g] - f_lo[g];
+                const int nch = (len + 255) >> 8;   // chunks of 256 products: four per lane
+                const int inc = wave_inclusive_scan_i32(nch);
+                const int total = __builtin_amdgcn_readlane(inc, 63);
+                const int choff = inc - nch;
+                constexpr int SQ = 4;   // chunks per turn and wave
+                for (int j0 = (wv - dealt) & (NW - 1); j0 < total; j0 += NW * SQ) {
+                    seg4 cq[SQ];
+                    int want[SQ], send[SQ];
+#pragma unroll
+                    for (int q = 0; q < SQ; q++) {
+                        const int j = j0 + q * NW;
+                        const int jc = j < total ? j : total - 1;
+                        // the entry of chunk jc: the last one with chunks whose first chunk is not after jc
+                        const unsigned long long m = __ballot(nch > 0 && choff <= jc);
+                        const int e = 63 - __clzll((long long)m);
+                        const int se = __builtin_amdgcn_readlane(s, e), le = __builtin_amdgcn_readlane(len, e);
+                        send[q] = j < total ? se + le : 0;   // a chunk past the end marks nothing
+                        want[q] = se + (jc - __builtin_amdgcn_readlane(choff, e)) * 256 + 4 * lane;
+                        cq[q] = ld_seg4(b_ix, want[q], se + le);   // unconditional load
+                    }
+#pragma unroll
+                    for (int q = 0; q < SQ; q++) sym_mark4(bits, cq[q], want[q], send[q], cbase);
                 }
-#pragma unroll
-                for (int q = 0; q < SQ; q++) sym_mark4(bits, cq[q], want[q], send[q], cbase);
+                dealt += total;
+                f_lo[g] = f_hi[g];
+                f_hi[g] = f_nx;
             }
-            f_lo = f_hi;
-            f_hi = f_nx;
         }
         for (int c = 0; c < (few ? 0 : npass); c++) {
             const int e = ((c << lgE) + el) * NW + wv;
