@@ -289,10 +289,10 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 }
 
 // ---------------------------------------------------------------------------
-// Symbolic phase of the light window rows: 256-thread workgroups of 28 KB, five per CU.  A row of few products in
+// Symbolic phase of the light window rows: 256-thread workgroups of 25 KB, six per CU.  A row of few products in
 // a wide matrix costs k_symd a fixed price per 2^20 columns (a pass over all entries and a count over the 128 KB
-// bitmap); here a window is cut by its S2_CAP products, whatever its width: the products go to registers and their
-// columns into a hash set of S2_TAB slots (linear probing, compare-and-swap on LDS; the set is at most half
+// bitmap); here a window is cut by its S2_CAP products, whatever its width: the products go to registers, four
+// consecutive ones of one entry per 16-byte load (ld_seg4), and their columns into a hash set of S2_TAB slots (linear probing, compare-and-swap on LDS; the set is at most half
 // full), and the row's count is the number of insertions that found an empty slot.  No ranks are needed to count,
 // so a window has three barriers (two for the directory that maps a product to its place in B, one before the set
 // is cleared) where a bitmap with rank prefixes has six.  A window that the products of one table window overfill,
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(THREADS) k_symd(const int32_t* __restrict__ li
 // most 2^16 columns and reads its products through the directory cursor instead.
 constexpr int S2_THREADS = 256, S2_U = 8, S2_CAP = S2_U * S2_THREADS, S2_TAB = 2 * S2_CAP, S2_TAB_LOG2 = 12;
 static_assert(S2_TAB == 1 << S2_TAB_LOG2, "the hash takes the top bits of a 32-bit product");
-__global__ void __launch_bounds__(S2_THREADS, 5) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+__global__ void __launch_bounds__(S2_THREADS, 6) k_sym2(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                         const int32_t* __restrict__ a_ix, const int32_t* __restrict__ b_ix,
                                                         const int32_t* __restrict__ winptr, int nbase, int shift,
                                                         int32_t* __restrict__ rowcnt) {
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(S2_THREADS, 5) k_sym2(const int32_t* __restric
     static_assert(U == 8, "eight 16-bit marks per thread move as one 16-byte piece");
     __shared__ __align__(16) uint32_t tab[S2_TAB];   // hash set of (column - first column of the window + 1), 0 = empty
     uint32_t* const fine = tab;                       // plain bitmap of the windows that do not take the set
-    __shared__ __align__(16) uint16_t emap[S2_CAP];
+    __shared__ __align__(16) uint16_t emap[S2_CAP / 4];   // pack -> entry + 1
     __shared__ int2 dirs[2][THREADS + 1];
     __shared__ uint32_t cs[1026];
     __shared__ int32_t tmp_a[NW + 1], tmp_c[NW + 1], wave_ent[NW], total_cnt;
@@ -350,12 +350,15 @@ __global__ void __launch_bounds__(S2_THREADS, 5) k_sym2(const int32_t* __restric
     // widest window in table windows: what the search below covers for the hash set of a single-chunk row, what the
     // plain bitmap covers otherwise
     const int gmax = single ? 256 : ((S2_CAP * 32) >> shift);
+    // products of a hash-set window: its lanes take the products in packs of four consecutive ones of one entry, an entry's
+    // last pack may hold one to three empty places, and the packs must fit the S2_CAP / 4 places of the directory's map
+    const uint32_t cap = (uint32_t)(S2_CAP - 3 * (lenA < THREADS ? lenA : THREADS));
     auto window_end = [&](int w0) {
         // a window of k table windows fits (monotone in k): lanes try 4, 8, .. 256, then three lanes the ones between
         const uint32_t base = cs[w0];
         auto fit = [&](int k) {
             const int jk = w0 + k < nbase ? w0 + k : nbase;
-            return k <= gmax && w0 + k <= nbase && cs[jk] - base <= (uint32_t)S2_CAP;
+            return k <= gmax && w0 + k <= nbase && cs[jk] - base <= cap;
         };
         const unsigned long long m1 = __ballot(fit(4 * (lane + 1)));
         const int c1 = m1 == ~0ull ? 64 : __ffsll(~m1) - 1;
@@ -387,52 +390,65 @@ __global__ void __launch_bounds__(S2_THREADS, 5) k_sym2(const int32_t* __restric
         }
         if (prod_w == 0u) continue;   // block-uniform
         const int wbase = w0 << shift;
-        if (single && prod_w <= (uint32_t)S2_CAP) {
+        if (single && prod_w <= cap) {
             // ---- hash set of the window's columns, products in registers ---------------------------------------
             // the directory alternates between two buffers, so its build needs no barrier in front
+            // dir[e] = {first pack of entry e | products of e << 12, where its segment starts}; emap: pack -> entry + 1
             flip ^= 1;
             int2* dir = dirs[flip];
-            ((uint4*)emap)[tid] = make_uint4(0u, 0u, 0u, 0u);
+            static_assert(S2_CAP / 4 == 2 * THREADS && S2_CAP < (1 << 12), "two packs per thread, 12 bits of products per entry");
+            ((uint32_t*)emap)[tid] = 0u;
             if (tid < NW) wave_ent[tid] = 0;
-            int Tc;
-            const int off = block_exclusive_scan_1b<THREADS, int32_t>(len, tmp_a, &Tc);
-            dir[tid] = make_int2(off, s);
-            if (len > 0) {
-                // where this entry's products start, and the 512-product slices that start inside it
+            const int np = (len + 3) >> 2;
+            int Tc;   // packs of the window
+            const int off = block_exclusive_scan_1b<THREADS, int32_t>(np, tmp_a, &Tc);
+            dir[tid] = make_int2(off | (len << 12), s);
+            constexpr int PW = 2 * 64;   // packs per wave
+            if (np > 0) {
+                // where this entry's packs start, and the wave slices that start inside it
                 emap[off] = (uint16_t)(tid + 1);
-                for (int b = off / (U * 64) + 1; b * (U * 64) < off + len; b++) wave_ent[b] = tid + 1;
+                for (int b = off / PW + 1; b * PW < off + np; b++) wave_ent[b] = tid + 1;
             }
             __syncthreads();
-            const int p_lo = wv * (U * 64);
-            const int p_hi = p_lo + U * 64 < Tc ? p_lo + U * 64 : Tc;
+            const int p_lo = wv * PW;
+            const int p_hi = p_lo + PW < Tc ? p_lo + PW : Tc;
             if (p_lo < p_hi) {   // wave-uniform
-                // running maximum of the marks over the slice = entry (+1) of every product
-                uint4* mine = (uint4*)(emap + p_lo + lane * U);
-                const uint4 raw = *mine;
-                int v[U] = {(int)(raw.x & 0xffffu), (int)(raw.x >> 16), (int)(raw.y & 0xffffu), (int)(raw.y >> 16),
-                            (int)(raw.z & 0xffffu), (int)(raw.z >> 16), (int)(raw.w & 0xffffu), (int)(raw.w >> 16)};
-#pragma unroll
-                for (int i = 1; i < U; i++) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
-                const int inc = wave_inclusive_max_nonneg(v[U - 1]);
+                // running maximum of the marks over the slice = entry (+1) of every pack
+                uint32_t* mine = (uint32_t*)(emap + p_lo + lane * 2);
+                const uint32_t raw = *mine;
+                int v0 = (int)(raw & 0xffffu), v1 = (int)(raw >> 16);
+                v1 = v1 > v0 ? v1 : v0;
+                const int inc = wave_inclusive_max_nonneg(v1);
                 int before = dpp_shr1(inc);
                 const int wb = wave_ent[wv];
                 before = (lane != 0 && before > wb) ? before : wb;
-#pragma unroll
-                for (int i = 0; i < U; i++) v[i] = v[i] > before ? v[i] : before;
-                *mine = make_uint4((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
-                                   (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16));
+                v0 = v0 > before ? v0 : before;
+                v1 = v1 > before ? v1 : before;
+                *mine = (uint32_t)v0 | ((uint32_t)v1 << 16);
                 wave_sync_lds();   // the other lanes of the wave read these entries next
-                int pos[U];
+                seg4 cq[2];
+                int lo[2], hi[2];
 #pragma unroll
-                for (int j = 0; j < U; j++) {
+                for (int j = 0; j < 2; j++) {
                     const int p = p_lo + j * 64 + lane;
-                    const int pc = p < p_hi ? p : p_hi - 1;   // lanes past the end repeat the slice's last product: found in the set
+                    const int pc = p < p_hi ? p : p_hi - 1;   // lanes past the end repeat the slice's last pack: found in the set
                     const int2 d = dir[(int)emap[pc] - 1];
-                    pos[j] = d.y + (pc - d.x);
+                    const int want = d.y + 4 * (pc - (d.x & 0xfff)), send = d.y + (d.x >> 12);
+                    cq[j] = ld_seg4(b_ix, want, send);
+                    lo[j] = want - cq[j].first;     // elements lo .. hi-1 of the load are the pack's products (at least one)
+                    hi[j] = send - cq[j].first;
                 }
                 uint32_t key[U], h[U], old[U];
 #pragma unroll
-                for (int j = 0; j < U; j++) key[j] = (uint32_t)(b_ix[pos[j]] - wbase) + 1u;
+                for (int j = 0; j < 2; j++) {
+                    const int c4[4] = {cq[j].v.x, cq[j].v.y, cq[j].v.z, cq[j].v.w};
+                    // a place of the pack without a product takes the pack's first product again: found in the set
+                    const int l0 = lo[j] > 0 ? lo[j] : 0;
+                    const int cf = l0 == 0 ? c4[0] : l0 == 1 ? c4[1] : l0 == 2 ? c4[2] : c4[3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        key[4 * j + k] = (uint32_t)(((k >= lo[j] && k < hi[j]) ? c4[k] : cf) - wbase) + 1u;
+                }
                 // the first probes of all eight keys go out together; a key that meets another one walks on alone
 #pragma unroll
                 for (int j = 0; j < U; j++) {
