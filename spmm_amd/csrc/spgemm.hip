@@ -48,6 +48,8 @@ __global__ void __launch_bounds__(256) k_pack_b12(const int32_t* __restrict__ b_
         r.z = (uint32_t)b_ix[p];
         *reinterpret_cast<uint3*>(b12 + 3 * p) = r;
     }
+    // four records of padding: a pack of four consecutive records (wave_pack_sweep) may start at the last entry
+    if (blockIdx.x == 0 && threadIdx.x < 12) b12[3 * nnz + threadIdx.x] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -615,7 +617,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     // numeric: B's entries as 12-byte records (the values are this call's)
     if (mode == BINS_NUMERIC && !slab && (out->n_w > 0 || out->n_g > 0) && B->nnz > 0) {
-        CHK(ws(ctx, WS_B12, (size_t)B->nnz * 3 + 4, &out->b12));
+        CHK(ws(ctx, WS_B12, (size_t)B->nnz * 3 + 12, &out->b12));
         // the records of the last packing serve when they were made from the same column ids and values (content
         // digests, read back with the counters above) and still lie where they were written
         const unsigned long long dig_v = (unsigned long long)h[CNT_DIG_VAL];

@@ -177,6 +177,52 @@ __device__ __forceinline__ void wave_flat_sweep(PIX b_ix, P12 b12, int s,
     if (R <= 0) between();
 }
 
+// The same sweep in packs of four consecutive products of one entry: lanes hold (s, rem) as above, an entry has
+// (rem + 3) / 4 packs, the packs of all entries form one index space, a batch is 64 of them, one per lane: a lane looks up
+// its entry once (one map byte, the entry's place, end and value of A from the lane that holds it) for up to four
+// products, where the product-by-product sweep pays these look-ups, all of them instructions of the LDS pipeline, per
+// product.  The four records are loaded whatever the pack holds (B's records end with four records of padding);
+// act(col, a*b, valid) is called four times per lane, valid for the products of the pack.  The map needs no second
+// round: entries mark the slot of their first pack, a lane reads its own slot, a running maximum over the lanes fills
+// the gaps.  between() as above.
+template <typename P12, typename F, typename G>
+__device__ __forceinline__ void wave_pack_sweep(P12 b12, int s, int rem, double a, int lane, uint8_t* wmap, F&& act, G&& between) {
+    rem = rem > 0 ? rem : 0;
+    const int np = (rem + 3) >> 2;
+    const int inc = wave_inclusive_scan_i32(np);
+    const int R = __builtin_amdgcn_readlane(inc, 63);
+    const int o = inc - np;      // index of the entry's first pack
+    const int so = s - 4 * o;    // pack q of this entry starts at record so + 4 q
+    const int send = s + rem;
+    for (int b0 = 0; b0 < R; b0 += 64) {
+        wmap[lane] = 0;
+        // (the marks follow the clearing in the LDS queue of this wave: no fence in between)
+        if (np > 0 && o >= b0 && o < b0 + 64) wmap[o - b0] = (uint8_t)(lane + 1);
+        // the entry that holds pack b0 when it started in an earlier batch (at most one lane)
+        const unsigned long long hold = __ballot(np > 0 && o < b0 && o + np > b0);
+        const int base = hold ? __ffsll(hold) : 0;
+        wave_sync_lds();   // the marks of the other lanes
+        int run = wave_inclusive_max_nonneg((int)wmap[lane]);
+        run = run > base ? run : base;
+        const int q = b0 + lane;
+        const bool live = q < R;
+        const int src = live ? run - 1 : 0;   // (lanes past the end: any lane, nothing of theirs is valid)
+        const int pos = __shfl(so, src, 64) + 4 * q;
+        const int pend_src = __shfl(send, src, 64);   // every lane takes part: a shuffle reads only from active lanes
+        const int pend = live ? pend_src : 0;
+        const int pc = live ? pos : 0;
+        const colval c0 = ld_b12(b12, pc), c1 = ld_b12(b12, pc + 1), c2 = ld_b12(b12, pc + 2), c3 = ld_b12(b12, pc + 3);
+        if (b0 == 0) between();
+        const double aj = __shfl(a, src, 64);   // fetched while the loads are in flight
+        act(c0.col, aj * c0.val, pos < pend);
+        act(c1.col, aj * c1.val, pos + 1 < pend);
+        act(c2.col, aj * c2.val, pos + 2 < pend);
+        act(c3.col, aj * c3.val, pos + 3 < pend);
+        wave_sync_lds();   // the map is cleared again at the top
+    }
+    if (R <= 0) between();
+}
+
 // 16-byte stores to addresses that are only element aligned (the compiler splits such a store; the hardware
 // takes it).  The no-op keeps the next instruction from overwriting the data registers too early.
 typedef int32_t v4i32 __attribute__((ext_vector_type(4)));

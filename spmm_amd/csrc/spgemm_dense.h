@@ -140,8 +140,9 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
     // table windows).  The other workgroups take one row of `list` each.
 #ifdef SPMM_DIAG
     const int dbg = dbg_arg >= 4 && dbg_arg <= 6 ? dbg_arg : 0;   // diagnostic build: entries per wave and pass forced to 2^dbg
+    const int dskip = dbg_arg >= 7 && dbg_arg <= 9 ? dbg_arg - 6 : 0;   // timing experiment (results are wrong): 1 no column-id stores, 2 no value stores, 3 neither
 #else
-    constexpr int dbg = 0;
+    constexpr int dbg = 0, dskip = 0;
     (void)dbg_arg;
 #endif
     const bool shared = blockIdx.x < (unsigned)n_shared;
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 const int rem = lane < E ? len - 2 * LA : 0;
                 unsigned long long mask_c = __ballot(rem > 256);
                 // tier 2: the rest of all entries with up to 256 more products, flattened over the wave
-                wave_flat_sweep<true>(nullptr, b12, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
+                wave_pack_sweep(b12, s + 2 * LA, rem <= 256 ? rem : 0, a, lane, wmap,
                                       [&](int col, double v, bool valid) { dense_add(acc, flags, col, cbase, v, valid); },
                                       [&] {
                                           dense_add(acc, flags, q0, cbase, a * r0, v0);
@@ -488,6 +489,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                 int32_t* const pi = c_ix + out + r;
                 double* const pv = c_val + out + r;
                 unsigned mm = m16;
+                if (!(dskip & 1))
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     if (__ballot(cnt > 4 * g) == 0ull) break;   // wave-uniform
@@ -505,6 +507,7 @@ __global__ void __launch_bounds__(THREADS) k_dense(const int32_t* __restrict__ l
                             if (cnt > 4 * g + j) pi[4 * g + j] = id[j];
                     }
                 }
+                if (!(dskip & 2))
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
                     if (__ballot(cnt > 2 * g) == 0ull) break;
