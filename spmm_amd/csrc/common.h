@@ -74,6 +74,22 @@ struct plan_cache {
     int l_row_beg = 0, l_row_end = 0;
     long long l_n_s = 0, l_n_t = 0, l_n_l = 0, l_n_m = 0, l_n_w = 0, l_n_g = 0, l_n_dense = 0, l_n_light = 0, l_products = 0, l_dense_entries = 0;
 
+    // Bound tables of the dense rows of one row range (spgemm_dense.h), kept from numeric call to numeric call on the same
+    // matrices: they depend on the structure of A and B alone.  An entry owns its device memory and carries the order of
+    // the rows its tables were gathered in (rows of equal product count come out of a classification in any order).
+    struct dense_tab {
+        int32_t row_beg, row_end;
+        long long n_g, n_dense, entries;
+        int nbase;
+        int32_t* rows;     // n_g shared rows, then n_dense others
+        int64_t* doff;     // entries of A before each of them, and the total
+        int32_t* dbound;
+        size_t bytes;
+    };
+    std::vector<dense_tab> dtabs;
+    size_t dtab_bytes = 0;
+    void drop_tables();   // frees them (ctx.hip)
+
     // A call that rebuilds the plan marks it untrusted first and trusted again only when it has run to its end, so that a
     // call that fails half way leaves nothing a later call could take for a plan.
     void begin_update() { valid = false; lists_valid = false; }
@@ -83,6 +99,7 @@ struct plan_cache {
         begin_update();
         has_wcnt = has_table = has_slab = b12_valid = false;
         n_giant = 0;
+        drop_tables();
     }
 };
 
@@ -115,6 +132,7 @@ struct spmm_ctx {
     long long slab_smax = 4194304;  // entries of B per window (its slab: 10 bytes an entry); fewer, heavier windows measured faster than L2-sized ones
     int dense_sparse = 8192;  // runs of table windows of a dense row with at most this many entries of C are one bitmap window (0 = off)
     int dense_bounds = 1;     // dense rows read their window bounds from per-row tables in sweep order, gathered from the window table by every numeric call
+    long long dense_keep_mib = 49152;   // device memory the kept bound tables of a plan may take (SPMM_DENSE_KEEP_MIB; 0: none are kept)
     long long dense_bounds_max = 32ll << 30;   // bytes of those tables per call; beyond, the dense kernel reads the window table itself
     int light_two = 1;        // light window rows: two-level windows (a bitmap bit per 32 columns, then a word per touched group)
     int win_dense_over = 1;   // 1024-thread cursor kernel: a table window with more products than a register-resident window takes dense accumulators

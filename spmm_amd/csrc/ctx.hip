@@ -71,6 +71,7 @@ int read_switches(spmm_ctx* c) {
     ok = ok && env_int("SPMM_DENSE_SPARSE", 0, 8192, &c->dense_sparse);         // entries of C; 0 = no sparse runs
     ok = ok && env_int("SPMM_DENSE_BOUNDS", 0, 1, &c->dense_bounds);
     ok = ok && env_int("SPMM_DENSE_BOUNDS_MAX", 0, 1ll << 46, &c->dense_bounds_max);   // bytes
+    ok = ok && env_int("SPMM_DENSE_KEEP_MIB", 0, 1ll << 26, &c->dense_keep_mib);
     ok = ok && env_int("SPMM_MAX_GRID_THREADS", 1024, (1ll << 32) - 1, &c->max_grid_threads);
     ok = ok && env_int("SPMM_CHAIN_PERSISTENT", 0, 1, &c->chain_persistent);
     ok = ok && env_int("SPMM_CHAIN_MAX_SPINS", 1, 1ll << 30, &c->chain_max_spins);
@@ -141,10 +142,21 @@ extern "C" int spmm_ctx_create(int device, spmm_ctx** out) {
     return SPMM_OK;
 }
 
+void plan_cache::drop_tables() {
+    for (dense_tab& t : dtabs) {   // hipFree waits for the device: no kernel still reads them
+        if (t.rows) hipFree(t.rows);
+        if (t.doff) hipFree(t.doff);
+        if (t.dbound) hipFree(t.dbound);
+    }
+    dtabs.clear();
+    dtab_bytes = 0;
+}
+
 extern "C" int spmm_ctx_destroy(spmm_ctx* c) {
     if (!c) return SPMM_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    c->plan.drop_tables();
     for (int i = 0; i < WS_NSLOTS; i++)
         if (c->slot[i]) hipFree(c->slot[i]);
     for (host_pool_buf& b : c->host_pool) hipFree(b.p);

@@ -408,6 +408,7 @@ struct Bins {
     bool slab;           // the window rows take the launches over B's slab order
     int nslots;          // (slab) numbered rows
     bool rebuilt;        // (slab) a numeric call found no matching plan: the slots are this call's own, without counts yet
+    int32_t row_end;     // the rows classified: [row_beg of the call, row_end)
 };
 
 // Column width of a table window: 2^14 columns (the width of the dense accumulators) while that
@@ -439,6 +440,7 @@ enum { BINS_PRODUCTS = 0, BINS_SYMBOLIC = 1, BINS_NUMERIC = 2 };
 int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, int mode, Bins* out) {
     const int32_t nrow = A->nrow;
     const bool fresh = mode != BINS_NUMERIC;
+    out->row_end = row_end;
     long long* counters;
     int ph = phase_begin(ctx, SPMM_PH_BINS);
     plan_cache& pc = ctx->plan;
@@ -519,6 +521,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     }
     // the lists of the last classification serve this call when it is over the same rows of the same matrices
     const bool reuse = hit && pc.lists_valid && pc.l_row_beg == row_beg && pc.l_row_end == row_end;
+    if (!hit) pc.drop_tables();   // kept bound tables are those of the plan's matrices
     pc.begin_update();
     out->rebuilt = !fresh && !hit;
     if (!hit && nrow > 0) {
@@ -736,7 +739,60 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         int32_t* dbound = nullptr;
         int64_t* doff = nullptr;
         double* dav = nullptr;
-        if (ctx->dense_bounds != 0 && bins.dense_entries > 0 && budget_entries > 0 && nd_rows < 0x7fffffffll) {
+        // the dense rows in the order their tables are in: this call's lists, or those of a kept set of tables
+        const int32_t *lg_base = bins.list_g, *lw_base = bins.list_w;
+        bool kept = false;   // the tables of this call's rows stand from an earlier call
+        if (ctx->dense_bounds != 0 && bins.dense_entries > 0 && nd_rows < 0x7fffffffll) {
+            // Kept tables: a numeric call over the same rows of the plan's matrices (the next step of an iteration) finds
+            // the tables of its dense rows where the last such call left them, and only gathers A's values again.
+            const bool keep_ok = !ctx->arena_on && ctx->dense_keep_mib > 0 && ctx->plan.valid;
+            const size_t need = (size_t)bins.dense_entries * wpr * 4 + ((size_t)nd_rows + 1) * 12 + 1024;
+            plan_cache::dense_tab* tab = nullptr;
+            if (keep_ok) {
+                for (plan_cache::dense_tab& t : ctx->plan.dtabs)
+                    if (t.row_beg == row_beg && t.row_end == bins.row_end && t.n_g == bins.n_g && t.n_dense == bins.n_dense &&
+                        t.entries == bins.dense_entries && t.nbase == bins.nbase) tab = &t;
+                kept = tab != nullptr;
+                if (!tab && ctx->plan.dtab_bytes + need <= (size_t)ctx->dense_keep_mib << 20) {
+                    // a new set, when the device has the memory to spare (a failed allocation is no error: the call
+                    // then gathers into its scratch as without the switch)
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)16 << 30)) {
+                        plan_cache::dense_tab t{};
+                        t.row_beg = row_beg; t.row_end = bins.row_end; t.n_g = bins.n_g; t.n_dense = bins.n_dense;
+                        t.entries = bins.dense_entries; t.nbase = bins.nbase; t.bytes = need;
+                        if (hipMalloc(&t.rows, ((size_t)nd_rows + 1) * 4) == hipSuccess && hipMalloc(&t.doff, ((size_t)nd_rows + 1) * 8) == hipSuccess &&
+                            hipMalloc(&t.dbound, ((size_t)bins.dense_entries * wpr + 1) * 4) == hipSuccess) {
+                            ctx->device_allocs += 3;
+                            if (bins.n_g > 0)
+                                HIPCHK(hipMemcpyAsync(t.rows, bins.list_g, sizeof(int32_t) * (size_t)bins.n_g, hipMemcpyDeviceToDevice, ctx->stream));
+                            if (bins.n_dense > 0)
+                                HIPCHK(hipMemcpyAsync(t.rows + bins.n_g, bins.list_w, sizeof(int32_t) * (size_t)bins.n_dense, hipMemcpyDeviceToDevice, ctx->stream));
+                            ctx->plan.dtabs.push_back(t);
+                            ctx->plan.dtab_bytes += need;
+                            tab = &ctx->plan.dtabs.back();
+                        } else {
+                            (void)hipGetLastError();
+                            if (t.rows) hipFree(t.rows);
+                            if (t.doff) hipFree(t.doff);
+                            if (t.dbound) hipFree(t.dbound);
+                        }
+                    }
+                }
+            }
+            if (tab) {
+                lg_base = tab->rows;
+                lw_base = tab->rows + bins.n_g;
+                doff = tab->doff;
+                dbound = tab->dbound;
+                if (!kept)
+                    hipLaunchKernelGGL(k_dense_offsets, dim3(1), dim3(1024), 0, ctx->stream, lg_base, (int)bins.n_g, lw_base, (int)bins.n_dense,
+                                       A->indptr, doff);
+                CHK(ws(ctx, WS_DAVAL, (size_t)bins.dense_entries + 1, &dav));
+                groups.push_back({0, nd_rows, 0, (int64_t)bins.dense_entries, true});
+            }
+        }
+        if (groups.empty() && ctx->dense_bounds != 0 && bins.dense_entries > 0 && budget_entries > 0 && nd_rows < 0x7fffffffll) {
             CHK(ws(ctx, WS_DOFF, (size_t)nd_rows + 1, &doff));
             hipLaunchKernelGGL(k_dense_offsets, dim3(1), dim3(1024), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w, (int)bins.n_dense,
                                A->indptr, doff);
@@ -765,7 +821,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                 CHK(ws(ctx, WS_DBOUND, most * wpr + 1, &dbound));
                 CHK(ws(ctx, WS_DAVAL, most + 1, &dav));
             }
-        } else groups.push_back({0, nd_rows, 0, 0, false});
+        } else if (groups.empty()) groups.push_back({0, nd_rows, 0, 0, false});
         unsigned long long* stamps;
         CHK(ws(ctx, WS_STAMPS, 32, &stamps));
         // rows with very many entries first, each shared by giant_tasks workgroups
@@ -777,9 +833,9 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             const bool lb = gr.lb;
             if (lb) {
                 const long long tiles = (gr.entries + 63) / 64;
-                hipLaunchKernelGGL(k_dense_bounds, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, bins.list_g, (int)bins.n_g, bins.list_w,
+                hipLaunchKernelGGL(k_dense_bounds, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, lg_base, (int)bins.n_g, lw_base,
                                    (int)bins.n_dense, A->indptr, A->indices, A->data, bins.winptr, bins.nbase, doff, (int)gr.i0, (int)gr.i1,
-                                   dbound, dav);
+                                   dbound, dav, kept ? 1 : 0);
             }
 #ifdef SPMM_DIAG
             auto kd = (ctx->win_stamps == 1 || ctx->win_stamps == 4) ? (lb ? k_dense<1024, true, true> : k_dense<1024, true, false>)
@@ -795,19 +851,19 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
                                    c_val, ctx->win_dbg >> 8, stamps, list_g, n_shared, gtasks, gchunk,
                                    bins.gslot, bins.wcnt, major ? (int)n_g : 0,
                                    ctx->dense_sparse < DENSE_SPARSE_VALS ? ctx->dense_sparse : DENSE_SPARSE_VALS, dbound, dav,
-                                   lb ? doff + (list_g - bins.list_g) : nullptr, lb ? doff + bins.n_g + (list_w - bins.list_w) : nullptr,
+                                   lb ? doff + (list_g - lg_base) : nullptr, lb ? doff + bins.n_g + (list_w - lw_base) : nullptr,
                                    gr.base);
             };
-            // the group's part of list_g and of list_w
+            // the group's part of the shared rows and of the others
             const long long g0 = gr.i0 < bins.n_g ? gr.i0 : bins.n_g, g1 = gr.i1 < bins.n_g ? gr.i1 : bins.n_g;
             const long long w0 = (gr.i0 > bins.n_g ? gr.i0 : bins.n_g) - bins.n_g, w1 = (gr.i1 > bins.n_g ? gr.i1 : bins.n_g) - bins.n_g;
-            if ((g1 - g0) * gtasks + (w1 - w0) <= max_wg) launch(bins.list_g + g0, g1 - g0, bins.list_w + w0, w1 - w0);
+            if ((g1 - g0) * gtasks + (w1 - w0) <= max_wg) launch(lg_base + g0, g1 - g0, lw_base + w0, w1 - w0);
             else {
                 // more workgroups than one grid dimension holds: the shared rows in slices, then the others
                 const long long per = max_wg / gtasks > 0 ? max_wg / gtasks : 1;
                 for (long long off = g0; off < g1; off += per)
-                    launch(bins.list_g + off, g1 - off < per ? g1 - off : per, bins.list_w, 0);
-                for_row_slices(ctx, w1 - w0, 1024, 1, [&](long long off, long long cnt) { launch(bins.list_g, 0, bins.list_w + w0 + off, cnt); });
+                    launch(lg_base + off, g1 - off < per ? g1 - off : per, lw_base, 0);
+                for_row_slices(ctx, w1 - w0, 1024, 1, [&](long long off, long long cnt) { launch(lg_base, 0, lw_base + w0 + off, cnt); });
             }
         }
         phase_end(ctx, phd);

@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(256) k_dense_bounds(const int32_t* __restrict_
                                                       int n_dense, const int32_t* __restrict__ a_ip, const int32_t* __restrict__ a_ix,
                                                       const double* __restrict__ a_val, const int32_t* __restrict__ winptr, int nbase,
                                                       const int64_t* __restrict__ doff, int i0, int i1, int32_t* __restrict__ dbound,
-                                                      double* __restrict__ dav) {
+                                                      double* __restrict__ dav, int values_only) {
+    // values_only: the tables stand (kept from an earlier call on the same structure), only A's values are gathered
     // list positions [i0, i1): their tables start at dbound[0], their values at dav[0]
     __shared__ int32_t tile[64][65];
     __shared__ int32_t krow[64], dlen[64];
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) k_dense_bounds(const int32_t* __restrict_
     __syncthreads();
     const int kl = krow[lane], ln = dlen[lane];
     const int64_t d = dst[lane];
-    for (int w0 = 0; w0 <= nbase; w0 += 64) {
+    for (int w0 = values_only ? nbase + 1 : 0; w0 <= nbase; w0 += 64) {
         for (int j = g; j < 64; j += 4) {
             const int k = krow[j], w = w0 + lane;
             tile[j][lane] = (k >= 0 && w <= nbase) ? winptr[(int64_t)k * tstride + w] : 0;

@@ -55,6 +55,8 @@ PLANS = {
     "split_rows_two_workgroups": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8", "SPMM_GIANT_MAJOR": "0", "SPMM_GIANT_TASKS": "2",
                                   "SPMM_GIANT_CHUNK": "3"},
     "table_budget_falls_back_to_slab": {"SPMM_TABLE_MAX_MIB": "1"},
+    "dense_tables_not_kept": {"SPMM_DENSE_MIN": "1", "SPMM_MAJOR_CHUNK": "4", "SPMM_DENSE_KEEP_MIB": "0"},
+    "dense_tables_kept_in_part": {"SPMM_DENSE_MIN": "1", "SPMM_DENSE_KEEP_MIB": "1"},
 }
 
 

@@ -1,8 +1,7 @@
 #!/bin/bash
 # scratch: variants of the current build
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-D="SPMM_LIB_PATH=build/diag/libspmm_hip.so SPMM_BENCH_NOCHECK=1"
-bash tools/runvar.sh dg0 22 $D SPMM_WIN_DBG=0 || exit 1
-bash tools/runvar.sh dg_noid 22 $D SPMM_WIN_DBG=$((7<<8)) || exit 1
-bash tools/runvar.sh dg_noval 22 $D SPMM_WIN_DBG=$((8<<8)) || exit 1
-bash tools/runvar.sh dg_nost 22 $D SPMM_WIN_DBG=$((9<<8)) || exit 1
+timeout -k 10 1100 python -u -m pytest tests/test_gpu_spgemm.py -x -q --timeout 300 --timeout-method thread > gpurun_out/exp_tests.log 2>&1 || { tail -15 gpurun_out/exp_tests.log; exit 1; }
+tail -2 gpurun_out/exp_tests.log
+bash tools/runvar.sh kp1 22 SPMM_NOP=1 || exit 1
+bash tools/runvar.sh kp1_24 24 SPMM_NOP=1 || exit 1
