@@ -1,7 +1,5 @@
 #!/bin/bash
 # scratch: variants of the current build
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout -k 10 1100 python -u -m pytest tests/test_gpu_spgemm.py -x -q --timeout 300 --timeout-method thread > gpurun_out/exp_tests.log 2>&1 || { tail -15 gpurun_out/exp_tests.log; exit 1; }
-tail -2 gpurun_out/exp_tests.log
-bash tools/runvar.sh kp1 22 SPMM_NOP=1 || exit 1
-bash tools/runvar.sh kp1_24 24 SPMM_NOP=1 || exit 1
+bash tools/runvar.sh l128 22 SPMM_LIB_PATH=build/l128/libspmm_hip.so || exit 1
+bash tools/runvar.sh l128_24 24 SPMM_LIB_PATH=build/l128/libspmm_hip.so || exit 1
