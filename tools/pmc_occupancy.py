@@ -22,10 +22,10 @@ for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive
             tot[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[m.group(1)][r["Counter_Name"]] += 1
 # allocation limits: (workgroups per CU, waves per workgroup, VGPRs, LDS bytes per workgroup)
-LIMITS = {"k_dense<1024, false, true>": (1, 16, 124, 151808), "k_win<1024, 8192, 8192, 8, 4, true, false, false>": (1, 16, 127, 155000),
-          "k_win<256, 2048, 2048, 8, 4, true, false, true>": (3, 4, 150, 51300), "k_sym2": (5, 4, 66, 28784),
-          "k_symd<1024>": (1, 16, 78, 135184), "k_escr<512, 4096, true>": (2, 8, None, 76000),
-          "k_escr<512, 4096, false>": (4, 8, None, 35000)}
+LIMITS = {"k_dense<1024, false, true>": (1, 16, 121, 151808), "k_win<1024, 8192, 8192, 8, 4, true, false, false>": (1, 16, 127, 155000),
+          "k_win<256, 2048, 2048, 8, 4, true, false, true>": (3, 4, 145, 51300), "k_sym2": (6, 4, 56, 25712),
+          "k_symd<1024>": (1, 16, 105, 135184), "k_escr<512, 4096, true>": (2, 8, 43, 76000),
+          "k_escr<512, 4096, false>": (4, 8, 38, 35000)}
 res = {}
 for k, c in tot.items():
     if "SQ_WAVE_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
