@@ -106,18 +106,22 @@ __global__ void __launch_bounds__(256) k_dense_bounds(const int32_t* __restrict_
     __syncthreads();
     const int kl = krow[lane], ln = dlen[lane];
     const int64_t d = dst[lane];
-    for (int w0 = values_only ? nbase + 1 : 0; w0 <= nbase; w0 += 64) {
+    if (values_only) return;
+    // windows 0 .. nbase-1 in tiles of 64; the last bound (the end of the row of B) on its own, so that a window count
+    // that is a multiple of 64 does not cost a whole turn for one column
+    for (int w0 = 0; w0 < nbase; w0 += 64) {
         for (int j = g; j < 64; j += 4) {
             const int k = krow[j], w = w0 + lane;
-            tile[j][lane] = (k >= 0 && w <= nbase) ? winptr[(int64_t)k * tstride + w] : 0;
+            tile[j][lane] = (k >= 0 && w < nbase) ? winptr[(int64_t)k * tstride + w] : 0;
         }
         __syncthreads();
         for (int wl = g; wl < 64; wl += 4) {
             const int w = w0 + wl;
-            if (kl >= 0 && w <= nbase) dbound[d + (int64_t)w * ln] = tile[lane][wl];
+            if (kl >= 0 && w < nbase) dbound[d + (int64_t)w * ln] = tile[lane][wl];
         }
         __syncthreads();
     }
+    if (tid < 64 && kl >= 0) dbound[d + (int64_t)nbase * ln] = winptr[(int64_t)kl * tstride + nbase];
 }
 
 #ifndef DENSE_TQ
