@@ -1,6 +1,7 @@
 #!/bin/bash
 # scratch: variants of the current build
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-bash tools/runvar.sh ts0 22 SPMM_TWO_STREAMS=0 || exit 1
-bash tools/runvar.sh ts1 22 SPMM_TWO_STREAMS=1 || exit 1
-RUNVAR_TIMEOUT=900 bash tools/runvar.sh ts1_24 24 SPMM_TWO_STREAMS=1 || exit 1
+D="SPMM_LIB_PATH=build/diag/libspmm_hip.so SPMM_BENCH_NOCHECK=1 SPMM_DENSE_SPARSE=0 SPMM_DENSE_KEEP_MIB=0"
+bash tools/runvar.sh loc0 22 $D SPMM_WIN_DBG=0 || exit 1
+bash tools/runvar.sh loc11 22 $D SPMM_WIN_DBG=$((11<<8)) || exit 1
+bash tools/runvar.sh loc12 22 $D SPMM_WIN_DBG=$((12<<8)) || exit 1
