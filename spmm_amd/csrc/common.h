@@ -132,7 +132,7 @@ struct spmm_ctx {
     long long slab_smax = 4194304;  // entries of B per window (its slab: 10 bytes an entry); fewer, heavier windows measured faster than L2-sized ones
     int dense_sparse = 8192;  // runs of table windows of a dense row with at most this many entries of C are one bitmap window (0 = off)
     int dense_bounds = 1;     // dense rows read their window bounds from per-row tables in sweep order, gathered from the window table by every numeric call
-    long long dense_keep_mib = 163840;  // device memory the kept bound tables of a plan may take (SPMM_DENSE_KEEP_MIB; 0: none are kept); a set is only kept while the device has 16 GiB to spare beyond it
+    long long dense_keep_mib = 163840;  // device memory the kept bound tables of a plan may take (SPMM_DENSE_KEEP_MIB; 0: none are kept); a set is only kept while an eighth of the device memory stays free beyond it
     long long dense_bounds_max = 32ll << 30;   // bytes of those tables per call; beyond, the dense kernel reads the window table itself
     int light_two = 1;        // light window rows: two-level windows (a bitmap bit per 32 columns, then a word per touched group)
     int win_dense_over = 1;   // 1024-thread cursor kernel: a table window with more products than a register-resident window takes dense accumulators
