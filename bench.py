@@ -171,7 +171,7 @@ def main():
     prod = torch.empty(n, dtype=torch.int64, device=dev)
     P_total = ctx.row_products_dev(vB, vB, prod)
     # rows of A per rank: equal shares of the intermediate products, weighted by the kernel class of the row
-    _, esc_max = capi.bin_limits()
+    esc_max = ctx.sort_limit(n)
     _, table_windows, dense_min_products = ctx.plan_info(n)
     bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min_products, max(ctx.light_max(n), esc_max),
                                         indptr[1:] - indptr[:-1], table_windows)
@@ -292,7 +292,7 @@ def main():
     # lightest).  The one with more time per step is reported, with the algorithmic bytes of its own rows:
     #   12 B per product (column id + value of B) + 20 B per entry of A (column id, value, two
     #   table bounds) + 12 B per row (row pointers of A and C) + 12 B per entry of C written.
-    esc_s, esc_l = capi.bin_limits()
+    esc_l = ctx.sort_limit(n)
     shift, nbase, dense_min = ctx.plan_info(n)
     pl = prod[r_lo:r_hi]
     lens_l = (indptr[r_lo + 1:r_hi + 1] - indptr[r_lo:r_hi]).to(torch.int64)

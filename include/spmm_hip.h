@@ -93,6 +93,10 @@ int spmm_ctx_phase_ms(spmm_ctx* ctx, int phase, double* total_ms, int* launches)
  * by the 64-lane expand-sort-compress kernel, rows with at most *esc_large by the larger
  * expand-sort-compress kernels, heavier rows by the window kernels. */
 void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large);
+/* Rows of A with at most this many intermediate products take the sorting kernels when the right-hand matrix has
+ * b_ncol columns: SPMM_ESC_MAX when set, else four products per table window of B between 1024 and 4096 (-1 on a
+ * null context).  Diagnostic, no counterpart in the reference. */
+int32_t spmm_spgemm_sort_limit(spmm_ctx* ctx, int32_t b_ncol);
 /* What a symbolic call keeps for the numeric calls that follow, and for the next symbolic call on the same matrices
  * (row products, row lists, the window table of B or its slab order, B's 12-byte records), is reused when sizes and
  * 64-bit content digests of the structure arrays (and of B's values, for the records) agree; the digests are the trust

@@ -151,6 +151,11 @@ class Context:
         """Drop everything kept between the calls of a product (the next call rebuilds it from its own arrays)."""
         _chk(lib().spmm_ctx_forget_plan(self._h))
 
+    def sort_limit(self, b_ncol):
+        """Rows with at most this many products take the sorting kernels for a right-hand matrix of b_ncol columns."""
+        lib().spmm_spgemm_sort_limit.restype = C.c_int32
+        return int(lib().spmm_spgemm_sort_limit(self._h, C.c_int32(int(b_ncol))))
+
     def plan_info(self, b_ncol):
         """(shift, nbase, dense_min_products) the context uses for a right-hand matrix of b_ncol columns."""
         sh, nb, dm = C.c_int32(), C.c_int32(), C.c_int64()

@@ -157,7 +157,7 @@ struct spmm_ctx {
     int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
     long long table_max_bytes = 96ll << 30;
     long long table_max_mib = -1;   // SPMM_TABLE_MAX_MIB, when set
-    int esc_max = 4096;     // rows of at most this many products take the sorting kernels (512 .. 8192)
+    int esc_max = -1;       // rows of at most this many products take the sorting kernels (512 .. 8192); < 0: by the number of table windows
     int win_dbg = 0;   // timing experiments of the window kernel (results are wrong when nonzero)
     std::vector<phase_rec> recs;       // recorded this profiling session
     std::vector<phase_rec> free_recs;  // event pairs ready for reuse

@@ -435,6 +435,13 @@ long long dense_threshold(const spmm_ctx* ctx, int nbase) {
     return d > 0xffffffffll ? 0xffffffffll : d;   // the sort key of the row order saturates there
 }
 
+// The sorting limit of a context for a product whose table has nbase windows.
+int sort_limit(const spmm_ctx* ctx, int nbase) {
+    if (ctx->esc_max > 0) return ctx->esc_max;
+    const long long e = (long long)ESC_PER_WINDOW * nbase;
+    return e < ESC_MAX_LOW ? ESC_MAX_LOW : e > ESC_MAX_DEFAULT ? ESC_MAX_DEFAULT : (int)e;
+}
+
 enum { BINS_PRODUCTS = 0, BINS_SYMBOLIC = 1, BINS_NUMERIC = 2 };
 
 int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_beg, int32_t row_end, int mode, Bins* out) {
@@ -554,7 +561,7 @@ int build_bins(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, int32_t row_
     if (!reuse) {
         if (nr > 0)
             hipLaunchKernelGGL(k_classify, dim3((unsigned)((nr + CLS_THREADS - 1) / CLS_THREADS)), dim3(CLS_THREADS), 0, ctx->stream, row_beg, row_end,
-                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, ctx->esc_max, giant_mode,
+                               out->prod, A->indptr, out->list_s, nrow, out->list_l, out->list_m, list_w0, key_w0, dense_thr, light_max, sort_limit(ctx, out->nbase), giant_mode,
                                major ? 0 : ctx->giant_len, out->gslot, list_g0, (slab && mode != BINS_PRODUCTS) ? 1 : 0, out->slot_row, key_g0, counters);
         HIPCHK(hipMemcpyAsync(h, counters, sizeof(long long) * CNT_N, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1008,9 +1015,19 @@ extern "C" int spmm_spgemm_light_max(spmm_ctx* ctx, int32_t b_ncol, int64_t* lig
     return SPMM_OK;
 }
 
-// The limits a context created now would use (it takes no context so that the host-side partitioning code can ask
-// without a GPU): SPMM_ESC_MAX when it holds an integer in [ESC_S_CAP, ESC_R_CAP], which is also the only kind of
-// value spmm_ctx_create accepts, else the default.
+// The sorting limit of ctx for a right-hand matrix of b_ncol columns (SPMM_ESC_MAX, or the rule by table windows).
+extern "C" int32_t spmm_spgemm_sort_limit(spmm_ctx* ctx, int32_t b_ncol) {
+    if (!ctx || b_ncol < 0) return -1;
+    const int sh = table_shift(b_ncol, ctx->dense_min);
+    int nb = (int)(((int64_t)b_ncol + (1ll << sh) - 1) >> sh);
+    if (nb < 1) nb = 1;
+    return sort_limit(ctx, nb);
+}
+
+// The limits that do not depend on the matrices (it takes no context so that host-side code can ask without a GPU): the
+// largest product count of the smallest sorting kernel, and SPMM_ESC_MAX when it holds an integer in
+// [ESC_S_CAP, ESC_R_CAP] (the only kind of value spmm_ctx_create accepts), else the upper end of the rule by table
+// windows.  The limit of a given product: spmm_spgemm_sort_limit.
 extern "C" void spmm_spgemm_bin_limits(int32_t* esc_small, int32_t* esc_large) {
     int lim = ESC_MAX_DEFAULT;
     if (const char* e = getenv("SPMM_ESC_MAX")) {

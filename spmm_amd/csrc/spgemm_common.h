@@ -15,7 +15,13 @@ constexpr int ESC_S_CAP = 512;
 #define ESC_T_LANES 8      // this many lanes each (8 x 64 measured best on web-sized graphs; 16 x 64: +5 %, 16 x 128: +10 %)
 #endif
 constexpr int ESC_L_CAP = 4096;
-constexpr int ESC_MAX_DEFAULT = 4096;   // spmm_ctx::esc_max (SPMM_ESC_MAX): measured at R-MAT-22: 8192 -> 4096 saves 17 ms of numeric and costs 9 ms of symbolic; lower limits cost more symbolic time than they save
+// Rows of up to this many products take the sorting kernels (spmm_ctx::esc_max, SPMM_ESC_MAX): four products per table
+// window of B, between 1024 and 4096.  A row just above the limit is a light window row, whose kernels pay per table
+// window it spans, so the break-even grows with the window count.  Measured with limits of 4096 / 1024: R-MAT-20 (64
+// windows) 124.8 / 123.2 ms per step, R-MAT-22 (256 windows) sorted rows 23.7 / 7.8 ms against light rows and their
+// symbolic phase 286.2 / 296.2 (-6 ms), R-MAT-24 (1024 windows) 91.7 / 23.3 against 3121 / 3276 (+87 ms); the
+// sx-askubuntu-sized graph (10 windows) 7.34 / 6.91 ms.
+constexpr int ESC_MAX_DEFAULT = 4096, ESC_MAX_LOW = 1024, ESC_PER_WINDOW = 4;
 constexpr int ESC_R_CAP = 8192;         // radix expand-sort-compress: rows with up to this many products and 65535 entries
 constexpr int WIN_SHIFT_MIN = 14;       // base column window of the table: 2^14 .. 2^17 columns
 constexpr int WIN_SHIFT_MAX = 17;

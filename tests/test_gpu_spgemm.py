@@ -48,6 +48,7 @@ PLANS = {
                            "SPMM_SLAB_THREADS": "256"},
     "cursor_overfull_windows_in_two_sweeps": {"SPMM_WIN_DENSE_OVER": "0"},
     "sorted_rows_up_to_8192": {"SPMM_ESC_MAX": "8192"},
+    "sorted_rows_up_to_4096": {"SPMM_ESC_MAX": "4096"},
     "sorted_rows_up_to_512": {"SPMM_ESC_MAX": "512"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
     "small_cursor_workgroups_one_level": {"SPMM_LIGHT_MAX": "65535", "SPMM_LIGHT_TWO": "0", "SPMM_LIGHT_SYM": "0"},

@@ -41,7 +41,7 @@ def main():
     vB = capi.dev_view(n, n, nnz, indptr, indices, data)
     prod = torch.empty(n, dtype=torch.int64, device=dev)
     P_total = ctx.row_products_dev(vB, vB, prod)
-    _, esc_max = capi.bin_limits()
+    esc_max = ctx.sort_limit(n)
     _, table_windows, dense_min = ctx.plan_info(n)
     bounds = shard.cost_balanced_bounds(prod, world, esc_max, dense_min, max(ctx.light_max(n), esc_max),
                                         indptr[1:] - indptr[:-1], table_windows)
