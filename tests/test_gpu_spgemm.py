@@ -554,6 +554,8 @@ def test_plan_threshold_follows_window_count():
         assert c.plan_info(1000) == (14, 1, 65536)
         shift, nbase, dmin = c.plan_info(1 << 27)
         assert (shift, nbase, dmin) == (17, 1024, 3072 * 1024)
+        # and the sorting kernels rows of up to four products per table window, between 1024 and 4096
+        assert [c.sort_limit(n) for n in (1000, 1 << 20, 1 << 22, 1 << 23, 1 << 24, 1 << 27)] == [1024, 1024, 1024, 2048, 4096, 4096]
     finally:
         c.close()
 
