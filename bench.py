@@ -199,9 +199,13 @@ def main():
             r0 = r1
         return blocks
 
+    c_ip_pinned = torch.empty(rows_l + 1, dtype=torch.int64, pin_memory=True)   # the row pointers of C come back through pinned memory
+
     def step(verify=False):
         nnz_c, _ = ctx.spgemm_symbolic_dev(vA, vB, c_ip)
-        c_ip_h = c_ip.cpu().numpy()
+        c_ip_pinned.copy_(c_ip, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        c_ip_h = c_ip_pinned.numpy()
         blocks = plan_blocks(c_ip_h)
         state.update(nnz_c=nnz_c, blocks=len(blocks), c_ip_h=c_ip_h)
         vsum, hsum = 0.0, 0
