@@ -150,10 +150,9 @@ struct spmm_ctx {
     long long max_grid_threads = (1ll << 32) - 1;   // grid dimension x workgroup size of one launch (lower: launches in slices)
     int split_giant = 1;    // split dense rows with very many entries over several workgroups (needs the symbolic counts)
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
-    int chain_persistent = 1;      // the greedy block chain in one persistent launch (0: one launch per step)
-    int chain_max_spins = 1 << 22; // polls of a workgroup waiting for the others before it gives up, and
-    long long chain_max_wait_ticks = 2000000;   // the same bound in ticks of the 100 MHz clock (20 ms; a step takes about 10 us)
-    bool chain_spins_forced = false;            // SPMM_CHAIN_MAX_SPINS was set: a give-up is then not remembered
+    int chain_sweep = 1;           // the greedy block chain as a two-pointer sweep over all row starts and a walk
+                                   // (0: one launch per step of the chain)
+    int sweep_chunks = -1;         // waves of the sweep (each counts one block's window first); -1: by the input's size
     int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
     long long table_max_bytes = 96ll << 30;
     long long table_max_mib = -1;   // SPMM_TABLE_MAX_MIB, when set

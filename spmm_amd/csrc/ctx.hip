@@ -73,8 +73,8 @@ int read_switches(spmm_ctx* c) {
     ok = ok && env_int("SPMM_DENSE_BOUNDS_MAX", 0, 1ll << 46, &c->dense_bounds_max);   // bytes
     ok = ok && env_int("SPMM_DENSE_KEEP_MIB", 0, 1ll << 26, &c->dense_keep_mib);
     ok = ok && env_int("SPMM_MAX_GRID_THREADS", 1024, (1ll << 32) - 1, &c->max_grid_threads);
-    ok = ok && env_int("SPMM_CHAIN_PERSISTENT", 0, 1, &c->chain_persistent);
-    ok = ok && env_int("SPMM_CHAIN_MAX_SPINS", 1, 1ll << 30, &c->chain_max_spins);
+    ok = ok && env_int("SPMM_CHAIN_SWEEP", 0, 1, &c->chain_sweep);
+    ok = ok && env_int("SPMM_SWEEP_CHUNKS", -1, 1 << 20, &c->sweep_chunks);
     ok = ok && env_int("SPMM_SLAB", -1, 1, &c->slab_mode);
     ok = ok && env_int("SPMM_TABLE_MAX_MIB", 0, 1ll << 30, &c->table_max_mib);  // window table of B beyond this: slab order
     ok = ok && env_int("SPMM_SLAB_WMAX", 64, 15360, &c->slab_wmax, 64);
@@ -89,7 +89,6 @@ int read_switches(spmm_ctx* c) {
     ok = ok && env_int("SPMM_WIN_STAMPS", 0, 4, &c->win_stamps);
 #endif
     if (!ok) return SPMM_E_ARG;
-    c->chain_spins_forced = getenv("SPMM_CHAIN_MAX_SPINS") != nullptr;
     if (c->table_max_mib >= 0) c->table_max_bytes = c->table_max_mib << 20;
     return SPMM_OK;
 }

@@ -98,15 +98,21 @@ __global__ void __launch_bounds__(256) k_row_keys_long(const int32_t* __restrict
                 if (lane == 0) before = prev_sec;
                 unsigned long long rise = __ballot(valid && sec > before);
                 const int nvalid = e - p0 < 64 ? e - p0 : 64;
-                int last = 0;                                     // elements of this chunk already counted
-                while (rise) {
-                    const int at = __ffsll(rise) - 1;
-                    rise &= rise - 1;
-                    score += at - last;                           // elements of the previous section
-                    last = at;
-                    if (score > best) { best = score; best_sec = __builtin_amdgcn_readlane(before, at); score = 0; }
+                // The score at a rise at lane `at` is off + at; the score only restarts at a rise where it beats the
+                // best, so the next restart is the first rise at a lane above best - off: one step per restart, not per
+                // rise (a row has at most sqrt(2 * length) restarts, each needs a longer run than the one before).
+                int off = score;
+                for (;;) {
+                    const int lo = best - off + 1 > 0 ? best - off + 1 : 0;
+                    if (lo >= 64) break;
+                    const unsigned long long m = rise & (~0ull << lo);
+                    if (!m) break;
+                    const int at = __ffsll(m) - 1;
+                    best = off + at;
+                    best_sec = __builtin_amdgcn_readlane(before, at);
+                    off = -at;
                 }
-                score += nvalid - last;
+                score = off + nvalid;
                 prev_sec = __builtin_amdgcn_readlane(sec, nvalid - 1);
             }
         }
@@ -166,14 +172,16 @@ int dev_gather_rows(spmm_ctx* ctx, int32_t n, const int32_t* perm, const int32_t
 }
 
 // ---------------------------------------------------------------------------
-// prev[p] = position of the previous occurrence of ix[p]'s column in the stream, or -1.
-// Input: the stream sorted by (column, position).
-__global__ void k_prev_from_sorted(int64_t n, const uint32_t* __restrict__ col_sorted, const uint32_t* __restrict__ pos_sorted,
-                                   int32_t* __restrict__ prev) {
+// pn[p] = (position of the previous occurrence of ix[p]'s column in the stream or -1, position of its next
+// occurrence or INT_MAX).  Input: the stream sorted by (column, position).  One 8-byte scattered store per element.
+__global__ void k_prev_next_from_sorted(int64_t n, const uint32_t* __restrict__ col_sorted, const uint32_t* __restrict__ pos_sorted,
+                                        int2* __restrict__ pn) {
     GRID_STRIDE(i, n) {
-        int32_t v = -1;
-        if (i > 0 && col_sorted[i - 1] == col_sorted[i]) v = (int32_t)pos_sorted[i - 1];
-        prev[pos_sorted[i]] = v;
+        const uint32_t c = col_sorted[i];
+        int2 v = make_int2(-1, INT_MAX);
+        if (i > 0 && col_sorted[i - 1] == c) v.x = (int32_t)pos_sorted[i - 1];
+        if (i + 1 < n && col_sorted[i + 1] == c) v.y = (int32_t)pos_sorted[i + 1];
+        pn[pos_sorted[i]] = v;
     }
 }
 
@@ -201,7 +209,7 @@ __global__ void k_block_chain_init(bc_state* st, int32_t* __restrict__ bsize, in
 }
 
 __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
-                                                                 const int32_t* __restrict__ prev, int32_t threshold,
+                                                                 const int2* __restrict__ pn, int32_t threshold,
                                                                  int32_t* __restrict__ bsize, int32_t cap, bc_state* st) {
     __shared__ int32_t tmp[BC_THREADS / 64 + 1];
     __shared__ int32_t sh_last, sh_cut;
@@ -212,7 +220,7 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
         const int q0 = pos + (int)blockIdx.x * BC_TILE + tid * BC_ITEMS;
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < BC_ITEMS; j++) c += (q0 + j < nnz && prev[q0 + j] < s0) ? 1 : 0;
+        for (int j = 0; j < BC_ITEMS; j++) c += (q0 + j < nnz && pn[q0 + j].x < s0) ? 1 : 0;
         c = wave_reduce_sum(c);
         if ((tid & 63) == 0) tmp[tid >> 6] = c;
         __syncthreads();
@@ -266,7 +274,7 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
     unsigned mask = 0;
 #pragma unroll
     for (int j = 0; j < BC_ITEMS; j++)
-        if (q0 + j < nnz && prev[q0 + j] < s0) mask |= 1u << j;
+        if (q0 + j < nnz && pn[q0 + j].x < s0) mask |= 1u << j;
     const int c = __popc(mask);
     int tot;
     const int ex = block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
@@ -309,10 +317,8 @@ __global__ void __launch_bounds__(BC_THREADS) k_block_chain_step(int32_t nrow, i
     }
 }
 
-// Row starts of the stream as a bitmap: bit p is set iff some row starts at stream position p.  The persistent chain
-// finds the end of the deciding element's row as the next set bit after it (one load) instead of searching the row
-// pointers (three dependent rounds), and records where each block starts in the stream; the rows are looked up after
-// the chain, all at once (k_cut_rows).
+// Row starts of the stream as a bitmap: bit p is set iff some row starts at stream position p.  The row that follows a
+// deciding element starts at the next set bit after it (one load instead of a search over the row pointers).
 __global__ void k_row_start_bits(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip, uint32_t* __restrict__ bits) {
     GRID_STRIDE(x, (int64_t)nrow + 1) {
         const int p = r_ip[x];
@@ -339,170 +345,143 @@ __global__ void k_cut_rows(int32_t nb, int32_t nrow, const int32_t* __restrict__
     }
 }
 
-// The same chain in ONE launch: BC_TILES workgroups stay resident and walk the steps together.  Per step every
-// workgroup counts its tile, publishes the count and arrives on a counter; the workgroup whose arrival is the last of
-// the step decides (as above) and publishes the new state and the step number; the others wait for that number.
-// Everything that crosses workgroups goes through agent-scope atomics and cache-bypassing (sc1) loads and stores, each
-// publication drained (s_waitcnt vmcnt(0)) before the counter or step number that announces it.  Waiting is bounded:
-// a workgroup that waits too long (the grid is not co-resident, e.g. on a shared GPU) raises `timeout`, every
-// workgroup leaves, and the host runs the chain step by step instead.
-struct bc_pstate {
-    int32_t s0, pos, cnt, nb, done, overflow;   // the chain's state after `gen` steps
-    int32_t gen, timeout, arrive, pad[7];
-    int32_t tile_cnt[2][BC_TILES];
-};
-__device__ __forceinline__ int32_t ld_sc1(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The chain without its serial steps.  For a block that starts at row start s let E(s) be the element that holds
+// its threshold-th new column; the next block starts at the first row start after E(s).  E is monotone in s, and the
+// number of new columns of the window [s, x), D(s, x) = #{q in [s, x) : prev[q] < s}, follows a move of s to the next
+// row start s' from the (prev, next) pairs of the row that leaves alone:
+//     D(s', x) = D(s, x) - #{q in [s, s') : prev[q] < s} + #{q in [s, s') : s' <= next[q] < x}
+// (the row's own first occurrences go, and its columns that come again inside the window are new there now).  So a
+// two-pointer sweep gives next_start[s] for EVERY row start: the rows are cut into chunks of equal weight, one wave
+// per chunk finds E of its first row by counting from there (the only redundant work: one window per chunk) and then
+// moves row by row, x only ever forward.  The chain itself is then a walk over next_start from position 0, one
+// dependent load per block (k_block_walk).  No workgroup waits for another anywhere.
+constexpr int SW_ROW_WEIGHT = 16;    // a row costs about as much as this many elements
+constexpr int SW_AHEAD = 8;          // loads in flight while a chunk counts its first window
 
-__global__ void k_block_chain_pinit(bc_pstate* st, int32_t* __restrict__ bsize, int32_t cap) {
-    if (threadIdx.x == 0) {
-        st->s0 = st->pos = st->cnt = 0;
-        st->nb = 1;
-        st->done = 0;
-        st->overflow = cap < 2 ? 1 : 0;
-        st->gen = st->timeout = st->arrive = 0;
-        if (cap >= 1) bsize[0] = 0;
+// first row r in [0, nrow] with r_ip[r] + SW_ROW_WEIGHT * r >= w
+__device__ __forceinline__ int sw_first_row(const int32_t* __restrict__ r_ip, int nrow, long long w) {
+    int lo = 0, hi = nrow;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)r_ip[mid] + (long long)SW_ROW_WEIGHT * mid >= w) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) k_block_sweep(int32_t nrow, int32_t nnz, const int32_t* __restrict__ r_ip,
+                                                     const int2* __restrict__ pn, const uint32_t* __restrict__ rs_bits,
+                                                     int32_t threshold, int32_t nchunk, int32_t* __restrict__ next_start) {
+    const int lane = threadIdx.x & 63;
+    const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (chunk >= nchunk) return;
+    const long long total = (long long)nnz + (long long)SW_ROW_WEIGHT * nrow;
+    const int ra = sw_first_row(r_ip, nrow, total * chunk / nchunk);
+    const int rb = chunk + 1 == nchunk ? nrow : sw_first_row(r_ip, nrow, total * (chunk + 1) / nchunk);
+    const unsigned long long le = (lanemask_lt() << 1) | 1ull;    // lanes up to and including this one
+    int ps = 0;                 // start of the previous non-empty row
+    int x = 0, cnt = 0;         // the window [start of the row at hand, x) holds cnt new columns
+    int ns = -1;                // first row start at or after the x it was looked up for
+    bool started = false, ended = false;
+    for (int r = ra; r < rb; r++) {
+        const int s = r_ip[r], e = r_ip[r + 1];
+        if (e == s) continue;
+        if (ended) {            // the stream ends before the window fills: so it does for every later start
+            if (lane == 0) next_start[s] = -1;
+            continue;
+        }
+        if (!started || x <= s) {
+            x = s;
+            cnt = 0;
+            started = true;
+        } else {
+            int gone = 0, back = 0;
+            for (int q0 = ps; q0 < s; q0 += 64) {
+                const int q = q0 + lane;
+                const bool v = q < s;
+                int2 a = make_int2(INT_MAX, INT_MAX);
+                if (v) a = pn[q];
+                gone += __popcll(__ballot(v && a.x < ps));
+                back += __popcll(__ballot(v && a.y >= s && a.y < x));
+            }
+            cnt += back - gone;
+        }
+        while (cnt < threshold && x < nnz) {
+            if (threshold - cnt > 64 * SW_AHEAD && x + 64 * SW_AHEAD <= nnz) {
+                int pv[SW_AHEAD];
+#pragma unroll
+                for (int j = 0; j < SW_AHEAD; j++) pv[j] = pn[x + j * 64 + lane].x;
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < SW_AHEAD; j++) c += __popcll(__ballot(pv[j] < s));
+                cnt += c;       // fewer than threshold still: every one of them could be new
+                x += 64 * SW_AHEAD;
+                continue;
+            }
+            const int q = x + lane;
+            const bool f = q < nnz && pn[q].x < s;
+            const unsigned long long b = __ballot(f);
+            const int c = __popcll(b);
+            if (cnt + c < threshold) {
+                cnt += c;
+                x = x + 64 < nnz ? x + 64 : nnz;
+            } else {            // the deciding element is the (threshold - cnt)-th new one of these 64
+                const int k = threshold - cnt;
+                const unsigned long long hit = __ballot(f && __popcll(b & le) == k);
+                x += __ffsll(hit);          // one past the deciding element
+                cnt = threshold;
+            }
+        }
+        if (cnt >= threshold) {
+            // next row start after the deciding element x - 1; the answer of the row before holds while x stays below it
+            if (x > ns) {
+                const int p0 = x;
+                int found = nnz;
+                for (int w0 = p0 >> 5; (long long)w0 * 32 < (long long)nnz; w0 += 64) {
+                    const int wi = w0 + lane;
+                    uint32_t bits = (long long)wi * 32 < (long long)nnz ? rs_bits[wi] : 0u;
+                    if (wi == (p0 >> 5)) bits &= ~0u << (p0 & 31);
+                    const unsigned long long m = __ballot(bits != 0u);
+                    if (m) {
+                        const int fl = __ffsll(m) - 1;
+                        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)bits, fl);
+                        found = (w0 + fl) * 32 + (__ffs(bw) - 1);
+                        break;
+                    }
+                }
+                ns = found < nnz ? found : nnz;
+            }
+            if (lane == 0) next_start[s] = ns;
+        } else {
+            ended = true;
+            if (lane == 0) next_start[s] = -1;
+        }
+        ps = s;
     }
 }
 
-__global__ void __launch_bounds__(BC_THREADS) k_block_chain_persistent(int32_t nnz, const uint32_t* __restrict__ rs_bits,
-                                                                       const int32_t* __restrict__ prev, int32_t threshold,
-                                                                       int32_t* __restrict__ cutpos, int32_t cap, bc_pstate* st,
-                                                                       int32_t max_spins, long long max_wait_ticks) {
-    static_assert(BC_TILES == 64, "one lane per tile count");
-    __shared__ int32_t tmp[BC_THREADS / 64 + 1];
-    __shared__ int32_t sh[8];          // s0, pos, cnt, nb, stop, last, hit, cut
-    const int tid = threadIdx.x;
-    int s0 = 0, pos = 0, cnt = 0, nb = 1;
-    if (tid == 0) sh[4] = (ld_sc1(&st->overflow) != 0) ? 1 : 0;
-    __syncthreads();
-    if (sh[4]) return;
-    for (int step = 0;; step++) {
-        // ---- this workgroup's tile ------------------------------------------------------------------------------------
-        {
-            const int q0 = pos + (int)blockIdx.x * BC_TILE + tid * BC_ITEMS;
-            int c = 0;
-#pragma unroll
-            for (int j = 0; j < BC_ITEMS; j++) c += (q0 + j < nnz && prev[q0 + j] < s0) ? 1 : 0;
-            c = wave_reduce_sum(c);
-            if ((tid & 63) == 0) tmp[tid >> 6] = c;
-            __syncthreads();
-            if (tid == 0) {
-                int tot = 0;
-                for (int i = 0; i < BC_THREADS / 64; i++) tot += tmp[i];
-                st_sc1(&st->tile_cnt[step & 1][blockIdx.x], tot);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int old = atomicAdd(&st->arrive, 1);
-                sh[5] = old == BC_TILES * (step + 1) - 1 ? 1 : 0;
-            }
-            __syncthreads();
+// The chain: cutpos[b] = stream position where block b starts, -1 closes the list.  state = {blocks, overflow}.
+__global__ void k_block_walk(int32_t nnz, const int32_t* __restrict__ next_start, int32_t* __restrict__ cutpos, int32_t cap,
+                             int32_t* __restrict__ state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int nb = 1, over = cap < 2 ? 1 : 0;
+    if (cap >= 1) cutpos[0] = 0;
+    int p = 0;
+    while (!over) {
+        const int n = p < nnz ? next_start[p] : -1;
+        if (n < 0) {                                   // end of the stream: the last block takes the rest
+            if (nb >= cap) over = 1; else cutpos[nb] = -1;
+            break;
         }
-        if (sh[5]) {
-            // ---- the last arrival of the step decides ---------------------------------------------------------------------
-            if (tid < 64) {
-                const int c = ld_sc1(&st->tile_cnt[step & 1][tid]);
-                int inc = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(inc, d, 64);
-                    inc += tid >= d ? o : 0;
-                }
-                const unsigned long long reach = __ballot(cnt + inc >= threshold);
-                const int first = reach ? __ffsll(reach) - 1 : -1;
-                if (tid == (first < 0 ? 63 : first)) {
-                    sh[6] = first;                       // deciding tile, or -1
-                    sh[7] = first < 0 ? inc : inc - c;   // new columns of the tiles before it (all tiles when none decides)
-                }
-            }
-            __syncthreads();
-            const int hit = sh[6], run = sh[7];
-            __syncthreads();
-            int n_s0 = s0, n_pos = pos, n_cnt = cnt, n_nb = nb, n_done = 0, n_over = 0;
-            if (hit < 0) {
-                n_cnt = cnt + run;
-                n_pos = pos + BC_TILES * BC_TILE;
-                if (n_pos >= nnz) {                                      // end of the stream: the last block takes the rest
-                    if (nb >= cap) n_over = 1; else if (tid == 0) cutpos[nb] = -1;
-                    n_done = 1;
-                }
-            } else {
-                const int target = threshold - cnt - run;
-                const int q0 = pos + hit * BC_TILE + tid * BC_ITEMS;
-                unsigned mask = 0;
-#pragma unroll
-                for (int j = 0; j < BC_ITEMS; j++)
-                    if (q0 + j < nnz && prev[q0 + j] < s0) mask |= 1u << j;
-                const int c = __popc(mask);
-                int tot;
-                const int ex = block_exclusive_scan<BC_THREADS, int32_t>(c, tmp, &tot);
-                if (ex < target && target <= ex + c) {
-                    unsigned m = mask;
-                    for (int k = target - ex; k > 1; k--) m &= m - 1u;
-                    sh[7] = q0 + (__ffs(m) - 1);
-                }
-                __syncthreads();
-                // the next block starts at the first row start after the deciding element
-                if (tid < 64) {
-                    const int p0 = sh[7] + 1;
-                    int found = nnz;
-                    for (int w0 = p0 >> 5; (long long)w0 * 32 < (long long)nnz; w0 += 64) {
-                        const int wi = w0 + tid;
-                        uint32_t bits = (long long)wi * 32 < (long long)nnz ? rs_bits[wi] : 0u;
-                        if (wi == (p0 >> 5)) bits &= ~0u << (p0 & 31);
-                        const unsigned long long m = __ballot(bits != 0u);
-                        if (m) {
-                            const int f = __ffsll(m) - 1;
-                            const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)bits, f);
-                            found = (w0 + f) * 32 + (__ffs(bw) - 1);
-                            break;
-                        }
-                    }
-                    if (tid == 0) sh[6] = found < nnz ? found : nnz;
-                }
-                __syncthreads();
-                const int ns = sh[6];
-                if (nb + 1 >= cap) {
-                    n_over = 1;
-                } else {
-                    if (tid == 0) cutpos[nb] = ns;
-                    n_nb = nb + 1;
-                    n_s0 = n_pos = ns;
-                    n_cnt = 0;
-                    if (ns >= nnz) {                                     // the stream ends with this cut
-                        if (nb + 2 > cap) n_over = 1; else if (tid == 0) cutpos[nb + 1] = -1;
-                        n_done = 1;
-                    }
-                }
-            }
-            if (tid == 0) {
-                st_sc1(&st->s0, n_s0); st_sc1(&st->pos, n_pos); st_sc1(&st->cnt, n_cnt); st_sc1(&st->nb, n_nb);
-                st_sc1(&st->done, n_done); st_sc1(&st->overflow, n_over);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                st_sc1(&st->gen, step + 1);
-            }
+        if (nb + 1 >= cap) { over = 1; break; }
+        cutpos[nb++] = n;
+        if (n >= nnz) {                                // the stream ends with this cut
+            if (nb + 1 > cap) over = 1; else cutpos[nb] = -1;
+            break;
         }
-        // ---- everybody: the state after this step ----------------------------------------------------------------------------
-        if (tid == 0) {
-            // a wait ends after max_spins polls or max_wait_ticks of the constant 100 MHz clock, whichever comes first
-            int spins = 0, stop = 0;
-            const long long t0 = (long long)wall_clock64();
-            while (ld_sc1(&st->gen) < step + 1) {
-                if (ld_sc1(&st->timeout) || ++spins > max_spins || ((spins & 31) == 0 && (long long)wall_clock64() - t0 > max_wait_ticks)) {
-                    st_sc1(&st->timeout, 1);
-                    stop = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            sh[0] = ld_sc1(&st->s0); sh[1] = ld_sc1(&st->pos); sh[2] = ld_sc1(&st->cnt); sh[3] = ld_sc1(&st->nb);
-            sh[4] = (stop || ld_sc1(&st->done) || ld_sc1(&st->overflow)) ? 1 : 0;
-        }
-        __syncthreads();
-        s0 = sh[0]; pos = sh[1]; cnt = sh[2]; nb = sh[3];
-        const int stop = sh[4];
-        __syncthreads();
-        if (stop) return;
+        p = n;
     }
+    state[0] = nb;
+    state[1] = over;
 }
 
 // ---------------------------------------------------------------------------
@@ -586,12 +565,20 @@ __global__ void k_panel_compact(int32_t bnum, const int32_t* __restrict__ bsize,
 // Panel sort, v8sort.h:152-232.
 __global__ void k_row_len_pid(int32_t nrow, const int32_t* __restrict__ r_ip, const int32_t* __restrict__ pstart, int32_t npanel,
                               uint32_t* __restrict__ len, uint32_t* __restrict__ pid, int32_t* __restrict__ maxlen) {
+    int longest = 0;
     GRID_STRIDE(r, nrow) {
         int l = r_ip[r + 1] - r_ip[r];
         len[r] = (uint32_t)l;
         pid[r] = (uint32_t)last_le(pstart, npanel, (int)r);
-        atomicMax(maxlen, l);
+        longest = l > longest ? l : longest;
     }
+    // one atomic per wave: four million atomics on one address were most of this kernel
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int o = __shfl_xor(longest, d, 64);
+        longest = o > longest ? o : longest;
+    }
+    if ((threadIdx.x & 63) == 0 && longest > 0) atomicMax(maxlen, longest);
 }
 
 __global__ void k_gather_u32(int64_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
@@ -777,53 +764,48 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
     int ph = phase_begin(ctx, SPMM_PH_BLOCKS);
     uint32_t *cs, *psd;
     CHK(sort_stream_by_col(ctx, r_ix, nnz, ncol, &cs, &psd));
-    int32_t* prev;
+    int2* pn;
     bc_state* st;
-    CHK(ws(ctx, WS_MISC1, (size_t)nnz + 1, &prev));
+    CHK(ws(ctx, WS_MISC1, 2 * ((size_t)nnz + 1), (int32_t**)&pn));
     CHK(ws(ctx, WS_COUNTERS, sizeof(bc_state) / sizeof(int32_t) + 1, (int32_t**)&st));
     if (nnz > 0)
-        hipLaunchKernelGGL(k_prev_from_sorted, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, prev);
+        hipLaunchKernelGGL(k_prev_next_from_sorted, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, pn);
     int32_t* h = (int32_t*)ctx->pinned;
-    if (ctx->chain_persistent) {
-        // the whole chain in one launch of BC_TILES resident workgroups; falls through to the stepwise form when a
-        // workgroup waited too long for the others (a grid that is not co-resident)
-        bc_pstate* ps;
+    if (ctx->chain_sweep) {
+        // next_start for every row start by the two-pointer sweep, then the walk; next_start lives in the sort's first
+        // key buffer, which is free again (the sorted stream is in the second pair)
         uint32_t* rs_bits;
-        int32_t* cutpos;
+        int32_t *cutpos, *next_start, *state;
         const size_t nwords = ((size_t)nnz + 31) / 32 + 64;
-        CHK(ws(ctx, WS_MISC3, sizeof(bc_pstate) / sizeof(int32_t) + 1, (int32_t**)&ps));
+        CHK(ws(ctx, WS_MISC3, 64, &state));
         CHK(ws(ctx, WS_MISC2, nwords, &rs_bits));
         CHK(ws(ctx, WS_MISC4, (size_t)cap + 1, &cutpos));
+        CHK(ws(ctx, WS_RADIX_K0, (size_t)nnz + 1, (uint32_t**)&next_start));
         HIPCHK(hipMemsetAsync(rs_bits, 0, nwords * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_row_start_bits, dim3(grid_for((int64_t)nrow + 1, 256)), dim3(256), 0, ctx->stream, nrow, nnz, r_ip, rs_bits);
-        hipLaunchKernelGGL(k_block_chain_pinit, dim3(1), dim3(64), 0, ctx->stream, ps, cutpos, cap);
-        hipLaunchKernelGGL(k_block_chain_persistent, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nnz, rs_bits, prev, threshold,
-                           cutpos, cap, ps, ctx->chain_max_spins, ctx->chain_max_wait_ticks);
-        HIPCHK(hipMemcpyAsync(h, ps, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        // a chunk counts one whole window (at least `threshold` elements) before it moves row by row, and its rows are
+        // a serial chain: 8192 waves (a full chip) unless the input is too small to give each a few rows
+        const long long weight = (long long)nnz + (long long)SW_ROW_WEIGHT * nrow;
+        long long nchunk = weight / 4096 + 1;
+        if (nchunk > 8192) nchunk = 8192;
+        if (ctx->sweep_chunks > 0) nchunk = ctx->sweep_chunks;      // as asked for; chunks without rows do nothing
+        if (nnz > 0)
+            hipLaunchKernelGGL(k_block_sweep, dim3((unsigned)((nchunk + 3) / 4)), dim3(256), 0, ctx->stream, nrow, nnz, r_ip, pn, rs_bits,
+                               threshold, (int32_t)nchunk, next_start);
+        hipLaunchKernelGGL(k_block_walk, dim3(1), dim3(64), 0, ctx->stream, nnz, next_start, cutpos, cap, state);
+        HIPCHK(hipMemcpyAsync(h, state, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (!h[7]) {     // no timeout
-            if (h[5]) {
-                phase_end(ctx, ph);
-                spmm_set_error("gen_blocks: more than %d blocks; the block list is too small", cap - 1);
-                return SPMM_E_CAPACITY;
-            }
-            if (!h[4]) {
-                phase_end(ctx, ph);
-                spmm_set_error("gen_blocks: the block chain ended without finishing");
-                return SPMM_E_HIP;
-            }
-            // the rows of the cuts, all at once
-            const int32_t nb = h[3];
-            hipLaunchKernelGGL(k_cut_rows, dim3(grid_for((int64_t)nb + 1, 256)), dim3(256), 0, ctx->stream, nb, nrow, r_ip, cutpos, bsize);
-            HIPCHK(hipGetLastError());
+        if (h[1]) {
             phase_end(ctx, ph);
-            *bnum_host = nb;
-            return SPMM_OK;
+            spmm_set_error("gen_blocks: more than %d blocks; the block list is too small", cap - 1);
+            return SPMM_E_CAPACITY;
         }
-        // A wait ran out: the 64 workgroups were not resident together (a GPU shared with other work).  Later calls of
-        // this context go straight to the stepwise form instead of waiting again (unless the poll bound was set from
-        // the environment, which is how the tests reach this path on every call).
-        if (!ctx->chain_spins_forced) ctx->chain_persistent = 0;
+        const int32_t nb = h[0];
+        hipLaunchKernelGGL(k_cut_rows, dim3(grid_for((int64_t)nb + 1, 256)), dim3(256), 0, ctx->stream, nb, nrow, r_ip, cutpos, bsize);
+        HIPCHK(hipGetLastError());
+        phase_end(ctx, ph);
+        *bnum_host = nb;
+        return SPMM_OK;
     }
     hipLaunchKernelGGL(k_block_chain_init, dim3(1), dim3(64), 0, ctx->stream, st, bsize, cap);
     // one launch per step of the chain; the number of steps (blocks + windows without a cut) is only
@@ -836,7 +818,7 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
             return SPMM_E_HIP;
         }
         for (int i = 0; i < 128; i++)
-            hipLaunchKernelGGL(k_block_chain_step, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, prev,
+            hipLaunchKernelGGL(k_block_chain_step, dim3(BC_TILES), dim3(BC_THREADS), 0, ctx->stream, nrow, nnz, r_ip, pn,
                                threshold, bsize, cap, st);
         HIPCHK(hipMemcpyAsync(h, st, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -14,10 +14,11 @@ STAGES = ["seq_bitmap", "r_indptr", "r_indices", "r_data", "bsize_list", "panel_
           "out_seq_all", "b_indptr", "b_colidx_orig", "b_data", "b_local", "keys", "seq_offset", "seq_input", "rseq"]
 
 
-# The greedy block chain as one persistent launch (default), as one launch per step, and as the persistent launch with a
-# spin limit of one poll, so that a workgroup gives up waiting for the others and the host falls back to the stepwise
-# form (every kernel still ends normally).
-CHAINS = {"persistent": {}, "stepwise": {"SPMM_CHAIN_PERSISTENT": "0"}, "persistent_gives_up": {"SPMM_CHAIN_MAX_SPINS": "1"}}
+# The greedy block chain as the two-pointer sweep over all row starts plus the walk (default: chunks by the input's
+# size), the same with one chunk (one wave sweeps every row) and with more chunks than rows (every chunk counts its own
+# window and moves over at most one row), and as one launch per step of the chain.
+CHAINS = {"sweep": {}, "sweep_one_chunk": {"SPMM_SWEEP_CHUNKS": "1"}, "sweep_chunk_per_row": {"SPMM_SWEEP_CHUNKS": "1048576"},
+          "stepwise": {"SPMM_CHAIN_SWEEP": "0"}}
 
 
 @pytest.fixture(scope="module", params=list(CHAINS))
