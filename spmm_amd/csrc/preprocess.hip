@@ -4,7 +4,7 @@
 //   row keys + stable bucket + row gather   bitmap.h:108-170        k_row_keys, radix sort, gather
 //   greedy row blocking                     transmat.h:334-376      prev-occurrence + k_block_chain
 //   panel boundaries                        v8sort.h:49-73          k_panel_list (prefix-min form)
-//   per-panel order + 8-row grouping        v8sort.h:152-232        two stable radix sorts + ranks
+//   per-panel order + 8-row grouping        v8sort.h:152-232        k_panel_sort: one workgroup per panel, in LDS
 //   block row gather + 8-row interleave     serial_newblock_clock.cpp:336-399   gather (fused)
 //   first-touch column renumbering          serial_newblock_clock.cpp:187-204   sort by (col,pos)
 //   write-back / fetch sequence             wbsort.h:16-95          compose / invert / gather
@@ -641,6 +641,143 @@ __global__ void k_panel_place(int32_t nrow, const uint32_t* __restrict__ sorted_
     }
 }
 
+// The same order by ONE workgroup per panel with everything in LDS (the panels are independent: this is the
+// segmented form of the sort).  Rows are put in 34 classes, the 33 short lengths and "long".  A first pass over the
+// panel counts the classes; a second pass, 1024 rows at a time in row order, ranks every row inside its class (lanes of
+// a wave that hold the same class find each other by ballots, per-wave class counts go through LDS), which places the
+// short rows at once.  The long rows are packed in row order as (length, rank) words and sorted in LDS by a bitonic
+// network; the rank in the low bits keeps equal lengths in row order.  A panel that does not fit (more than PS_LONG_CAP
+// long rows, more than 65 536 rows, or length and rank that do not fit one word) raises `unfit` and the caller runs
+// the two global sorts instead.
+__device__ __forceinline__ int bits_for_dev(uint32_t v) { return v ? 32 - __clz(v) : 1; }   // bits_for() on the device
+constexpr int PS_THREADS = 1024, PS_WAVES = PS_THREADS / 64, PS_CLASSES = 34, PS_LONG_CAP = 8192;
+
+__global__ void __launch_bounds__(PS_THREADS) k_panel_sort(const int32_t* __restrict__ r_ip, const int32_t* __restrict__ pstart,
+                                                           const int32_t* __restrict__ pend, const int32_t* __restrict__ pblock,
+                                                           const int32_t* __restrict__ bsize, int32_t* __restrict__ out_seq,
+                                                           int8_t* __restrict__ grp, int32_t* __restrict__ spv8,
+                                                           int32_t* __restrict__ unfit) {
+    __shared__ uint32_t key[PS_LONG_CAP];
+    __shared__ uint16_t rowof[PS_LONG_CAP];
+    __shared__ int32_t cnt[PS_CLASSES];              // rows per class
+    __shared__ int32_t gpre[33], rpre[33];           // grouped / leftover rows of shorter lengths
+    __shared__ int32_t run[PS_CLASSES];              // rows of the class in the tiles before this one
+    __shared__ int32_t wcnt[PS_WAVES][PS_CLASSES];
+    __shared__ int32_t tot[4];                       // [0] grouped rows, [2] longest row
+    const int pid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ps = pstart[pid], n = pend[pid] - ps;
+    const int row0 = ps - bsize[pblock[pid]];        // block-local id of the panel's first row
+    const int32_t* ipp = r_ip + ps;
+    if (tid < PS_CLASSES) { cnt[tid] = 0; run[tid] = 0; }
+    if (tid < 4) tot[tid] = 0;
+    __syncthreads();
+    const unsigned long long lt = lanemask_lt();
+    // ---- pass 1: rows per class, longest row
+    {
+        int longest = 0;
+        for (int i0 = 0; i0 < n; i0 += PS_THREADS) {
+            const int i = i0 + tid;
+            const bool v = i < n;
+            const int L = v ? ipp[i + 1] - ipp[i] : 0;
+            const int c = L < 33 ? L : 33;
+            longest = L > longest ? L : longest;
+            unsigned long long m = __ballot(v);
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const unsigned long long bb = __ballot((c >> b) & 1);
+                m &= ((c >> b) & 1) ? bb : ~bb;
+            }
+            if (v && (m & lt) == 0) atomicAdd(&cnt[c], __popcll(m));
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int o = __shfl_xor(longest, d, 64);
+            longest = o > longest ? o : longest;
+        }
+        if (lane == 0) atomicMax(&tot[2], longest);
+    }
+    __syncthreads();
+    if (w == 0) {       // prefixes over the short lengths
+        const int c = lane < 33 ? cnt[lane] : 0;
+        const int full = c - c % 8, rem = c % 8;
+        const int ig = wave_inclusive_scan(full), ir = wave_inclusive_scan(rem);
+        if (lane < 33) { gpre[lane] = ig - full; rpre[lane] = ir - rem; }
+        if (lane == 63) tot[0] = ig;
+    }
+    __syncthreads();
+    const int G = tot[0], nlong = cnt[33];
+    const int rank_bits = bits_for_dev(nlong > 0 ? (uint32_t)(nlong - 1) : 0u);
+    if (nlong > PS_LONG_CAP || n > 65536 || (nlong > 0 && bits_for_dev((uint32_t)tot[2]) + rank_bits > 32)) {
+        if (tid == 0) atomicAdd(unfit, 1);
+        return;
+    }
+    if (tid == 0) spv8[pid] = G;
+    // ---- pass 2: rank inside the class, in row order
+    for (int i0 = 0; i0 < n; i0 += PS_THREADS) {
+        for (int k = tid; k < PS_WAVES * PS_CLASSES; k += PS_THREADS) (&wcnt[0][0])[k] = 0;
+        __syncthreads();
+        const int i = i0 + tid;
+        const bool v = i < n;
+        const int L = v ? ipp[i + 1] - ipp[i] : 0;
+        const int c = L < 33 ? L : 33;
+        unsigned long long m = __ballot(v);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const unsigned long long bb = __ballot((c >> b) & 1);
+            m &= ((c >> b) & 1) ? bb : ~bb;
+        }
+        const int rank = __popcll(m & lt);
+        if (v && rank == 0) wcnt[w][c] = __popcll(m);
+        __syncthreads();
+        if (tid < PS_CLASSES) {        // per class: the waves' counts -> where each wave starts, and the running total
+            int base = run[tid];
+#pragma unroll
+            for (int ww = 0; ww < PS_WAVES; ww++) { const int x = wcnt[ww][tid]; wcnt[ww][tid] = base; base += x; }
+            run[tid] = base;
+        }
+        __syncthreads();
+        if (v) {
+            const int rho = wcnt[w][c] + rank;     // rows of the class before this one
+            if (c < 33) {
+                const int cn = cnt[c], full = cn - cn % 8;
+                int opos, g = -1;
+                if (rho < full) { opos = gpre[c] + rho; g = opos & 7; }
+                else opos = G + rpre[c] + (rho - full);
+                out_seq[ps + opos] = row0 + i;
+                grp[ps + opos] = (int8_t)g;
+            } else {
+                key[rho] = ((uint32_t)L << rank_bits) | (uint32_t)rho;
+                rowof[rho] = (uint16_t)i;
+            }
+        }
+        __syncthreads();
+    }
+    if (nlong == 0) return;
+    // ---- long rows by (length, row)
+    int P = 1;
+    while (P < nlong) P <<= 1;
+    for (int k = nlong + tid; k < P; k += PS_THREADS) key[k] = 0xffffffffu;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += PS_THREADS) {
+                const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));     // index with the stride bit clear
+                const int hi = lo | stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int C32 = n - nlong;       // grouped and leftover short rows come first
+    for (int j = tid; j < nlong; j += PS_THREADS) {
+        const int i = rowof[key[j] & ((1u << rank_bits) - 1u)];
+        out_seq[ps + C32 + j] = row0 + i;
+        grp[ps + C32 + j] = (int8_t)-1;
+    }
+}
+
 // perm2[t] = global source row of output row t; block-local row pointers per block.
 __global__ void k_perm2(int32_t nrow, const int32_t* __restrict__ out_seq, const int32_t* __restrict__ bsize, int32_t bnum,
                         int32_t* __restrict__ perm2) {
@@ -861,16 +998,31 @@ int dev_panels(spmm_ctx* ctx, int32_t nrow, int32_t bnum, const int32_t* bsize, 
     CHK(ws(ctx, WS_MISC6, (size_t)np + 1, &P->pblock));
     hipLaunchKernelGGL(k_panel_compact, dim3(bnum), dim3(256), 0, ctx->stream, bnum, bsize, padded, P->panel_ptr, P->panel_list,
                        P->pstart, P->pend, P->pblock);
-    // (length, row) then (panel) stable sorts -> (panel, length, row) order
-    uint32_t *len, *pid, *k0, *v0, *k1, *v1;
     int32_t* maxlen;
+    CHK(ws(ctx, WS_COUNTERS, 64, &maxlen));
+    if (np > 0) {
+        // every panel by one workgroup in LDS; `unfit` counts the panels that did not fit
+        int32_t* unfit = maxlen + 8;
+        HIPCHK(hipMemsetAsync(unfit, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_panel_sort, dim3(np), dim3(PS_THREADS), 0, ctx->stream, r_ip, P->pstart, P->pend, P->pblock, bsize,
+                           P->out_seq, P->grp, P->spv8, unfit);
+        HIPCHK(hipMemcpyAsync(h, unfit, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (h[0] == 0) {
+            HIPCHK(hipGetLastError());
+            phase_end(ctx, ph);
+            return SPMM_OK;
+        }
+    }
+    // some panel did not fit (or there is none): (length, row) then (panel) stable sorts of all rows -> (panel, length,
+    // row) order, which rewrites every panel's outputs
+    uint32_t *len, *pid, *k0, *v0, *k1, *v1;
     CHK(ws(ctx, WS_MISC7, (size_t)nrow + 1, &len));
     CHK(ws(ctx, WS_P0, (size_t)nrow + 1, &pid));
     CHK(ws(ctx, WS_RADIX_K0, (size_t)nrow + 1, &k0));
     CHK(ws(ctx, WS_RADIX_V0, (size_t)nrow + 1, &v0));
     CHK(ws(ctx, WS_RADIX_K1, (size_t)nrow + 1, &k1));
     CHK(ws(ctx, WS_RADIX_V1, (size_t)nrow + 1, &v1));
-    CHK(ws(ctx, WS_COUNTERS, 64, &maxlen));
     HIPCHK(hipMemsetAsync(maxlen, 0, 64 * sizeof(int32_t), ctx->stream));
     if (nrow > 0) {
         hipLaunchKernelGGL(k_row_len_pid, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, r_ip, P->pstart, np, len, pid, maxlen);

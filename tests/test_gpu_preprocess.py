@@ -102,6 +102,29 @@ def test_pipeline_edge_cases(ctx):
     _compare(g, o)
 
 
+def test_panel_with_more_long_rows_than_the_lds_sort_holds(ctx):
+    """10 000 rows of 33 entries in one section (one bucket, so they stay together) beside rows that carry ten times
+    their entries: one panel then holds more than the 8192 long rows the per-panel sort keeps in LDS, and the call
+    falls back to the two global sorts.  The outputs are the oracle's either way."""
+    rng = np.random.default_rng(12)
+    n, short = 20480, 10000
+    row = [np.repeat(np.arange(short), 33)]
+    col = [np.tile(np.arange(33), short)]
+    for r in range(short, n):
+        c = rng.choice(n, 315, replace=False)
+        row.append(np.full(c.size, r))
+        col.append(c)
+    ip, ix, d = orc.csr_from_coo(n, np.concatenate(row), np.concatenate(col))
+    o = orc.trace_formats(n, ip, ix, d, sort_mode=1)
+    lens = np.diff(o["r_indptr"])
+    most = 0
+    for b in range(o["bnum"]):
+        lst = o["panel_list"][o["panel_ptr"][b]:o["panel_ptr"][b + 1]] + o["bsize_list"][b]
+        most = max([most] + [int((lens[lo:hi] >= 33).sum()) for lo, hi in zip(lst[:-1], lst[1:])])
+    assert most > 8192
+    _compare(ctx.trace_formats(capi.Csr(n, n, ip, ix, d)), o)
+
+
 def test_pipeline_block_capacity_is_an_error(ctx):
     n = 1 << 11
     row, col = synth.rmat(11, 8, 21, True)
