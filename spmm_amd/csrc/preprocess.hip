@@ -129,44 +129,69 @@ __global__ void k_perm_lens(int32_t n, const int32_t* __restrict__ perm, const i
     GRID_STRIDE(t, n) { int s = perm[t]; lens[t] = ip[s + 1] - ip[s]; }
 }
 
-constexpr int GR_ROWS = 256;   // output rows per workgroup
-__global__ void __launch_bounds__(256) k_gather_rows(int32_t n, const int32_t* __restrict__ perm,
+// One workgroup per GR_CHUNK consecutive ELEMENTS of the output (not per run of rows: a hub row of 10^5 entries was one
+// workgroup's tail of most of a millisecond).  The workgroup finds the rows that overlap its chunk by two 64-way
+// searches over the output row pointers, takes them GR_ROWS at a time into LDS and finds every element's row there.
+constexpr int GR_CHUNK = 8192, GR_ROWS = 1024;
+
+// last index i in [0, cnt) with a[i] <= v; a is non-decreasing and a[0] <= v.  All 64 lanes call it with the same arguments.
+__device__ __forceinline__ int wave_last_le(const int32_t* __restrict__ a, int cnt, int v) {
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = cnt;                       // a[lo] <= v; a[hi] > v or hi == cnt
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;   // probes at lo + step, lo + 2 step, ...
+        const int idx = lo + (lane + 1) * step;
+        const int c = __popcll(__ballot(idx < hi && a[idx] <= v));      // true for the first c lanes
+        const int nlo = lo + c * step;
+        hi = nlo + step < hi ? nlo + step : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) k_gather_rows(int32_t n, int32_t nnz, const int32_t* __restrict__ perm,
                                                      const int32_t* __restrict__ src_ip, const int32_t* __restrict__ src_ix,
                                                      const double* __restrict__ src_val, const int32_t* __restrict__ dst_ip,
                                                      int32_t* __restrict__ dst_ix, double* __restrict__ dst_val,
                                                      const int8_t* __restrict__ grp) {
-    __shared__ int32_t d0[GR_ROWS + 1];
-    __shared__ int32_t s0[GR_ROWS];
-    const int t0 = blockIdx.x * GR_ROWS;
-    const int nr = n - t0 < GR_ROWS ? n - t0 : GR_ROWS;
-    const int base = dst_ip[t0];
-    for (int i = threadIdx.x; i <= nr; i += 256) d0[i] = dst_ip[t0 + i] - base;
-    for (int i = threadIdx.x; i < nr; i += 256) s0[i] = src_ip[perm[t0 + i]];
-    __syncthreads();
-    const int total = d0[nr];
-    for (int p = threadIdx.x; p < total; p += 256) {
-        const int j = last_le(d0, nr, p);        // row of element p (d0[nr] = total > p)
-        const int r = p - d0[j];
-        const int src = s0[j] + r;
-        int dst = base + p;
-        if (grp != nullptr) {
-            const int c = grp[t0 + j];
-            if (c >= 0) dst = dst_ip[t0 + j - c] + 8 * r + c;
+    __shared__ int32_t d0[GR_ROWS + 1];         // output row pointers of the rows at hand
+    __shared__ int32_t s0[GR_ROWS];             // where their source rows start
+    const int p0 = blockIdx.x * GR_CHUNK;
+    const int p1 = nnz - p0 < GR_CHUNK ? nnz : p0 + GR_CHUNK;
+    // rows [t_lo, t_hi]: t_lo holds element p0, t_hi holds element p1 - 1 (dst_ip[n] = nnz > p1 - 1)
+    const int t_lo = wave_last_le(dst_ip, n + 1, p0);
+    const int t_hi = wave_last_le(dst_ip, n + 1, p1 - 1);
+    for (int tb = t_lo; tb <= t_hi; tb += GR_ROWS) {
+        const int nr = t_hi + 1 - tb < GR_ROWS ? t_hi + 1 - tb : GR_ROWS;
+        __syncthreads();
+        for (int i = threadIdx.x; i <= nr; i += 256) d0[i] = dst_ip[tb + i];
+        for (int i = threadIdx.x; i < nr; i += 256) s0[i] = src_ip[perm[tb + i]];
+        __syncthreads();
+        const int e0 = d0[0] > p0 ? d0[0] : p0, e1 = d0[nr] < p1 ? d0[nr] : p1;
+        for (int p = e0 + (int)threadIdx.x; p < e1; p += 256) {
+            const int j = last_le(d0, nr, p);        // row of element p (d0[0] <= p < d0[nr])
+            const int r = p - d0[j];
+            const int src = s0[j] + r;
+            int dst = p;
+            if (grp != nullptr) {
+                const int c = grp[tb + j];
+                if (c >= 0) dst = (j >= c ? d0[j - c] : dst_ip[tb + j - c]) + 8 * r + c;
+            }
+            dst_ix[dst] = src_ix[src];
+            dst_val[dst] = src_val[src];
         }
-        dst_ix[dst] = src_ix[src];
-        dst_val[dst] = src_val[src];
     }
 }
 
-int dev_gather_rows(spmm_ctx* ctx, int32_t n, const int32_t* perm, const int32_t* src_ip, const int32_t* src_ix,
+int dev_gather_rows(spmm_ctx* ctx, int32_t n, int32_t nnz, const int32_t* perm, const int32_t* src_ip, const int32_t* src_ix,
                     const double* src_val, int32_t* dst_ip, int32_t* dst_ix, double* dst_val, const int8_t* grp) {
     int32_t* lens;
     CHK(ws(ctx, WS_MISC0, (size_t)n + 1, &lens));
     if (n > 0) hipLaunchKernelGGL(k_perm_lens, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, perm, src_ip, lens);
     CHK(dev_exclusive_scan_i32(ctx, lens, dst_ip, n));
-    if (n > 0)
-        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + GR_ROWS - 1) / GR_ROWS)), dim3(256), 0, ctx->stream, n, perm,
-                           src_ip, src_ix, src_val, dst_ip, dst_ix, dst_val, grp);
+    if (n > 0 && nnz > 0)
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)(((int64_t)nnz + GR_CHUNK - 1) / GR_CHUNK)), dim3(256), 0, ctx->stream, n, nnz,
+                           perm, src_ip, src_ix, src_val, dst_ip, dst_ix, dst_val, grp);
     HIPCHK(hipGetLastError());
     return SPMM_OK;
 }
@@ -890,7 +915,7 @@ int dev_bitmap_reorder(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t* 
         hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)n);
         CHK(dev_radix_sort_pairs(ctx, k0, v0, k1, (uint32_t*)seq, n, bits_for((uint32_t)(A->ncol / sect))));
     }
-    CHK(dev_gather_rows(ctx, n, seq, A->indptr, A->indices, A->data, r_ip, r_ix, r_val, nullptr));
+    CHK(dev_gather_rows(ctx, n, A->nnz, seq, A->indptr, A->indices, A->data, r_ip, r_ix, r_val, nullptr));
     phase_end(ctx, ph);
     return SPMM_OK;
 }
@@ -1054,12 +1079,12 @@ int dev_panels(spmm_ctx* ctx, int32_t nrow, int32_t bnum, const int32_t* bsize, 
 }
 
 // gather + interleave: perm2[nrow], g_ip[nrow+1] scratch outputs; b_indptr[nrow+bnum], b_colidx, b_data
-int dev_pack(spmm_ctx* ctx, int32_t nrow, int32_t bnum, const int32_t* bsize, const int32_t* r_ip, const int32_t* r_ix,
+int dev_pack(spmm_ctx* ctx, int32_t nrow, int32_t nnz, int32_t bnum, const int32_t* bsize, const int32_t* r_ip, const int32_t* r_ix,
              const double* r_val, const int32_t* out_seq, const int8_t* grp, int32_t* perm2, int32_t* g_ip,
              int32_t* b_indptr, int32_t* b_colidx, double* b_data) {
     int ph = phase_begin(ctx, SPMM_PH_PACK);
     if (nrow > 0) hipLaunchKernelGGL(k_perm2, dim3(grid_for(nrow, 256)), dim3(256), 0, ctx->stream, nrow, out_seq, bsize, bnum, perm2);
-    CHK(dev_gather_rows(ctx, nrow, perm2, r_ip, r_ix, r_val, g_ip, b_colidx, b_data, grp));
+    CHK(dev_gather_rows(ctx, nrow, nnz, perm2, r_ip, r_ix, r_val, g_ip, b_colidx, b_data, grp));
     hipLaunchKernelGGL(k_block_indptr, dim3(bnum), dim3(256), 0, ctx->stream, bnum, bsize, g_ip, b_indptr);
     HIPCHK(hipGetLastError());
     phase_end(ctx, ph);
@@ -1203,7 +1228,7 @@ extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect
     CHK(dalloc(g, ctx, (size_t)n + bnum, &b_indptr));
     CHK(dalloc(g, ctx, z, &b_colidx));
     CHK(dalloc(g, ctx, z, &b_data));
-    CHK(dev_pack(ctx, n, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, b_indptr, b_colidx, b_data));
+    CHK(dev_pack(ctx, n, nnz, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, b_indptr, b_colidx, b_data));
     CHK(dalloc(g, ctx, z, &b_local));
     CHK(dalloc(g, ctx, z, &keys));
     CHK(dalloc(g, ctx, (size_t)bnum + 1, &seq_offset));
@@ -1375,7 +1400,7 @@ extern "C" int spmm_panels_sort_pack(spmm_ctx* ctx, const spmm_csr* R, const int
     CHK(dalloc(g, ctx, z, &d_bval));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     CHK(dev_panels(ctx, R->nrow, bnum, bsize, r_ip, &P));
-    CHK(dev_pack(ctx, R->nrow, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, d_bip, d_bix, d_bval));
+    CHK(dev_pack(ctx, R->nrow, R->nnz, bnum, bsize, r_ip, r_ix, r_val, P.out_seq, P.grp, perm2, g_ip, d_bip, d_bix, d_bval));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (n_panel_entries) *n_panel_entries = P.n_list;
     if (n_spv8) *n_spv8 = P.npanel;
