@@ -860,6 +860,120 @@ __global__ void k_seq_offset(int32_t bnum, const int32_t* __restrict__ bnnz, con
     GRID_STRIDE(b, bnum + 1) seq_offset[b] = gid[bnnz[b]];
 }
 
+// The same renumbering block by block in LDS.  The stream is sorted by (block, column, position) instead: a block's
+// elements then fill the same index range in the sorted arrays as in the stream, the runs of one column are the
+// first-touch candidates of that block alone, and one workgroup per block keeps the block's first-touch flags as a
+// bitmap with per-word prefix counts in LDS, so the number of first touches before a position is two LDS reads.  No
+// flags, ranks or run heads go through global memory; the scattered stores of `local` stay inside the block's own
+// range.  A block of more than RN_CAP elements raises `unfit` (the caller then runs the whole-stream form above).
+constexpr int RN_THREADS = 1024, RN_WAVES = RN_THREADS / 64, RN_PER = 4, RN_TILE = RN_THREADS * RN_PER, RN_CAP = 1 << 19;
+
+__global__ void k_block_col_keys(int64_t n, const int32_t* __restrict__ stream, const int32_t* __restrict__ bnnz, int32_t bnum,
+                                 int col_bits, uint32_t* __restrict__ keys) {
+    GRID_STRIDE(p, n) {
+        const int b = last_le(bnnz, bnum + 1, (int)p);
+        keys[p] = ((uint32_t)b << col_bits) | (uint32_t)stream[p];
+    }
+}
+
+// counts[b] = columns of block b = runs of equal keys in its range of the sorted stream
+__global__ void __launch_bounds__(256) k_block_head_counts(const uint32_t* __restrict__ cs, const int32_t* __restrict__ bnnz,
+                                                           int32_t* __restrict__ counts) {
+    __shared__ int32_t tmp[4];
+    const int b = blockIdx.x, e0 = bnnz[b], e1 = bnnz[b + 1];
+    int c = 0;
+    for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) c += (i == e0 || cs[i - 1] != cs[i]) ? 1 : 0;
+    c = wave_reduce_sum(c);
+    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+}
+
+__global__ void __launch_bounds__(RN_THREADS) k_renumber_block(const uint32_t* __restrict__ cs, const uint32_t* __restrict__ psd,
+                                                               const int32_t* __restrict__ bnnz, const int32_t* __restrict__ seq_offset,
+                                                               uint32_t col_mask, int32_t* __restrict__ local,
+                                                               int32_t* __restrict__ keys, int32_t* __restrict__ unfit) {
+    __shared__ uint32_t bits[RN_CAP / 32];          // bit q: the element at block position q is a first touch
+    __shared__ int32_t wpre[RN_CAP / 32];           // first touches in the words before
+    __shared__ int32_t tmp[RN_WAVES + 1];
+    __shared__ int32_t whead[RN_WAVES];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int e0 = bnnz[b], m = bnnz[b + 1] - e0;
+    if (m <= 0) return;
+    if (m > RN_CAP) {
+        if (tid == 0) atomicAdd(unfit, 1);
+        return;
+    }
+    const uint32_t* __restrict__ ck = cs + e0;
+    const uint32_t* __restrict__ cp = psd + e0;
+    const int nw = (m + 31) >> 5;
+    for (int k = tid; k < nw; k += RN_THREADS) bits[k] = 0u;
+    __syncthreads();
+    for (int i = tid; i < m; i += RN_THREADS) {
+        if (i == 0 || ck[i - 1] != ck[i]) {
+            const int q = (int)cp[i] - e0;
+            atomicOr(&bits[q >> 5], 1u << (q & 31));
+        }
+    }
+    __syncthreads();
+    {   // prefix counts: a thread sums a run of consecutive words
+        const int per = (nw + RN_THREADS - 1) / RN_THREADS;
+        const int k0 = tid * per < nw ? tid * per : nw, k1 = k0 + per < nw ? k0 + per : nw;
+        int mine = 0;
+        for (int k = k0; k < k1; k++) mine += __popc(bits[k]);
+        int tot;
+        int ex = block_exclusive_scan<RN_THREADS, int32_t>(mine, tmp, &tot);
+        for (int k = k0; k < k1; k++) { wpre[k] = ex; ex += __popc(bits[k]); }
+    }
+    __syncthreads();
+    const int key0 = seq_offset[b];
+    const unsigned long long lt = lanemask_lt();
+    int carry = -1;     // block position of the head of the run that is open where the tile starts
+    for (int t0 = 0; t0 < m; t0 += RN_TILE) {
+        const int i0 = t0 + tid * RN_PER;
+        uint32_t k[RN_PER];
+        int q[RN_PER];
+        bool head[RN_PER];
+        const uint32_t kprev = i0 > 0 && i0 < m ? ck[i0 - 1] : 0u;
+        int lh = -1;    // this thread's last head
+#pragma unroll
+        for (int j = 0; j < RN_PER; j++) {
+            const bool v = i0 + j < m;
+            k[j] = v ? ck[i0 + j] : 0u;
+            q[j] = v ? (int)cp[i0 + j] - e0 : -1;
+            head[j] = v && (i0 + j == 0 || k[j] != (j ? k[j - 1] : kprev));
+            if (head[j]) lh = q[j];
+        }
+        const unsigned long long any = __ballot(lh >= 0);
+        const unsigned long long below = any & lt;
+        const int from_lane = __shfl(lh, below ? 63 - __clzll((long long)below) : 0, 64);     // every lane shuffles; the choice comes after
+        const int top = __shfl(lh, any ? 63 - __clzll((long long)any) : 0, 64);
+        if (lane == 0) whead[w] = any ? top : -1;
+        __syncthreads();
+        int cur = carry, out = carry;
+#pragma unroll
+        for (int ww = 0; ww < RN_WAVES; ww++) {
+            const int h = whead[ww];
+            if (h >= 0) {
+                out = h;
+                if (ww < w) cur = h;
+            }
+        }
+        if (below) cur = from_lane;
+#pragma unroll
+        for (int j = 0; j < RN_PER; j++) {
+            if (i0 + j < m) {
+                if (head[j]) cur = q[j];
+                const int lid = wpre[cur >> 5] + __popc(bits[cur >> 5] & ((1u << (cur & 31)) - 1u));
+                local[e0 + q[j]] = lid;
+                if (head[j]) keys[key0 + lid] = (int32_t)(k[j] & col_mask);
+            }
+        }
+        carry = out;
+        __syncthreads();    // whead is written again in the next tile
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Write-back sequence, wbsort.h:58-67, 16-34, 81-95.
 __global__ void k_rseq(int32_t nrow, const int32_t* __restrict__ seq_bitmap, const int32_t* __restrict__ perm2, int32_t* __restrict__ rseq) {
@@ -1096,14 +1210,47 @@ int dev_first_touch(spmm_ctx* ctx, int32_t ncol, int32_t nnz, int32_t bnum, cons
                     const int32_t* stream, int32_t* local, int32_t* keys, int32_t* seq_offset, int32_t* nkeys_host) {
     int ph = phase_begin(ctx, SPMM_PH_RENUMBER);
     uint32_t *cs, *psd;
-    CHK(sort_stream_by_col(ctx, stream, nnz, ncol, &cs, &psd));
-    int32_t *bnnz, *first, *hidx, *hrun, *gid;
+    int32_t* bnnz;
+    int32_t* h = (int32_t*)ctx->pinned;
     CHK(ws(ctx, WS_MISC3, (size_t)bnum + 2, &bnnz));
+    hipLaunchKernelGGL(k_block_nnz_starts, dim3(grid_for(bnum + 1, 256)), dim3(256), 0, ctx->stream, bnum, bsize, r_ip, bnnz);
+    const int col_bits = bits_for(ncol > 0 ? (uint32_t)(ncol - 1) : 0u), blk_bits = bits_for(bnum > 1 ? (uint32_t)(bnum - 1) : 0u);
+    if (ctx->renumber_lds && nnz > 0 && bnum > 0 && col_bits + blk_bits <= 32) {
+        // block by block in LDS, from the stream sorted by (block, column, position)
+        uint32_t *k0, *v0;
+        int32_t *counts, *unfit;
+        CHK(ws(ctx, WS_RADIX_K0, (size_t)nnz + 1, &k0));
+        CHK(ws(ctx, WS_RADIX_V0, (size_t)nnz + 1, &v0));
+        CHK(ws(ctx, WS_RADIX_K1, (size_t)nnz + 1, &cs));
+        CHK(ws(ctx, WS_RADIX_V1, (size_t)nnz + 1, &psd));
+        CHK(ws(ctx, WS_MISC1, (size_t)bnum + 2, &counts));
+        CHK(ws(ctx, WS_COUNTERS, 64, &unfit));
+        HIPCHK(hipMemsetAsync(unfit, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(k_block_col_keys, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, stream, bnnz, bnum, col_bits, k0);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)nnz);
+        CHK(dev_radix_sort_pairs(ctx, k0, v0, cs, psd, nnz, col_bits + blk_bits));
+        hipLaunchKernelGGL(k_block_head_counts, dim3(bnum), dim3(256), 0, ctx->stream, cs, bnnz, counts);
+        CHK(dev_exclusive_scan_i32(ctx, counts, seq_offset, bnum));     // seq_offset[bnum] = number of keys
+        const uint32_t col_mask = col_bits >= 32 ? 0xffffffffu : (1u << col_bits) - 1u;
+        hipLaunchKernelGGL(k_renumber_block, dim3(bnum), dim3(RN_THREADS), 0, ctx->stream, cs, psd, bnnz, seq_offset, col_mask, local, keys,
+                           unfit);
+        HIPCHK(hipMemcpyAsync(h, seq_offset + bnum, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h + 1, unfit, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        if (h[1] == 0) {
+            *nkeys_host = h[0];
+            phase_end(ctx, ph);
+            return SPMM_OK;
+        }
+        // some block is too large for LDS: everything again over the whole stream
+    }
+    CHK(sort_stream_by_col(ctx, stream, nnz, ncol, &cs, &psd));
+    int32_t *first, *hidx, *hrun, *gid;
     CHK(ws(ctx, WS_MISC1, (size_t)nnz + 1, &first));
     CHK(ws(ctx, WS_MISC2, (size_t)nnz + 1, &hidx));
     CHK(ws(ctx, WS_MISC7, (size_t)nnz + 1, &hrun));
     CHK(ws(ctx, WS_P6, (size_t)nnz + 2, &gid));
-    hipLaunchKernelGGL(k_block_nnz_starts, dim3(grid_for(bnum + 1, 256)), dim3(256), 0, ctx->stream, bnum, bsize, r_ip, bnnz);
     if (nnz > 0)
         hipLaunchKernelGGL(k_first_flags, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, bnnz, bnum, first, hidx);
     CHK(dev_exclusive_scan_i32(ctx, first, gid, nnz));      // gid[nnz] = number of keys
@@ -1112,7 +1259,6 @@ int dev_first_touch(spmm_ctx* ctx, int32_t ncol, int32_t nnz, int32_t bnum, cons
         hipLaunchKernelGGL(k_renumber, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, cs, psd, hrun, gid, bnnz,
                            bnum, local, keys);
     hipLaunchKernelGGL(k_seq_offset, dim3(grid_for(bnum + 1, 256)), dim3(256), 0, ctx->stream, bnum, bnnz, gid, seq_offset);
-    int32_t* h = (int32_t*)ctx->pinned;
     HIPCHK(hipMemcpyAsync(h, gid + nnz, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *nkeys_host = h[0];

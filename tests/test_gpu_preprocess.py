@@ -18,7 +18,9 @@ STAGES = ["seq_bitmap", "r_indptr", "r_indices", "r_data", "bsize_list", "panel_
 # size), the same with one chunk (one wave sweeps every row) and with more chunks than rows (every chunk counts its own
 # window and moves over at most one row), and as one launch per step of the chain.
 CHAINS = {"sweep": {}, "sweep_one_chunk": {"SPMM_SWEEP_CHUNKS": "1"}, "sweep_chunk_per_row": {"SPMM_SWEEP_CHUNKS": "1048576"},
-          "stepwise": {"SPMM_CHAIN_SWEEP": "0"}}
+          "stepwise": {"SPMM_CHAIN_SWEEP": "0"},
+          # the first-touch renumbering over the whole stream at once instead of block by block in LDS
+          "renumber_whole_stream": {"SPMM_RENUMBER_LDS": "0"}}
 
 
 @pytest.fixture(scope="module", params=list(CHAINS))
@@ -122,6 +124,19 @@ def test_panel_with_more_long_rows_than_the_lds_sort_holds(ctx):
         lst = o["panel_list"][o["panel_ptr"][b]:o["panel_ptr"][b + 1]] + o["bsize_list"][b]
         most = max([most] + [int((lens[lo:hi] >= 33).sum()) for lo, hi in zip(lst[:-1], lst[1:])])
     assert most > 8192
+    _compare(ctx.trace_formats(capi.Csr(n, n, ip, ix, d)), o)
+
+
+def test_block_with_more_elements_than_the_lds_renumbering_holds(ctx):
+    """1000 rows of 600 entries over 61 000 columns never reach 65 536 distinct columns: one block of 600 000 elements,
+    more than the 524 288 the block-local renumbering keeps flags for, so the call renumbers over the whole stream."""
+    rng = np.random.default_rng(13)
+    n = 61000
+    row = np.repeat(rng.choice(n, 1000, replace=False), 600)
+    col = np.concatenate([rng.choice(n, 600, replace=False) for _ in range(1000)])
+    ip, ix, d = orc.csr_from_coo(n, row, col)
+    o = orc.trace_formats(n, ip, ix, d, sort_mode=1)
+    assert o["bnum"] == 1 and ix.size > 524288
     _compare(ctx.trace_formats(capi.Csr(n, n, ip, ix, d)), o)
 
 
