@@ -45,14 +45,18 @@ __device__ __forceinline__ int last_le(const int32_t* __restrict__ a, int n, int
 // previous element's and the running score beats the best, the PREVIOUS section becomes the
 // best and the score restarts (only then); key = best section + 1.
 // Rows of up to RK_LONG entries: one thread per row walks it; longer rows are listed for the
-// wave kernel below.
-constexpr int RK_LONG = 128, RK_AHEAD = 8;
+// wave kernel below, rows of more than RK_GIANT entries for the workgroup kernel after it.
+constexpr int RK_LONG = 128, RK_GIANT = 2048, RK_AHEAD = 8;
 __global__ void __launch_bounds__(256) k_row_keys(int32_t nrow, const int32_t* __restrict__ ip,
                                                   const int32_t* __restrict__ ix, int32_t sect,
                                                   uint32_t* __restrict__ keys, int32_t* __restrict__ long_rows,
                                                   int32_t* __restrict__ n_long) {
     GRID_STRIDE(r, nrow) {
         const int b = ip[r], e = ip[r + 1];
+        if (e - b > RK_GIANT) {               // listed from the back of the same array
+            long_rows[nrow - 1 - atomicAdd(n_long + 1, 1)] = (int32_t)r;
+            continue;
+        }
         if (e - b > RK_LONG) {
             long_rows[atomicAdd(n_long, 1)] = (int32_t)r;
             continue;
@@ -117,6 +121,60 @@ __global__ void __launch_bounds__(256) k_row_keys_long(const int32_t* __restrict
             }
         }
         if (lane == 0) keys[r] = (uint32_t)(best_sec + 1);
+    }
+}
+
+// Rows of more than RK_GIANT entries, one workgroup per row: a hub row of 10^5 entries was 190 dependent rounds of
+// one wave.  The four waves take 2048 entries per round and leave the section rises as 32 ballots in LDS (the section
+// before an entry is read from the row itself, so the rounds do not depend on each other); every thread then walks the
+// restarts of that round, which keeps the state uniform without another exchange.
+__global__ void __launch_bounds__(256) k_row_keys_giant(int32_t nrow, const int32_t* __restrict__ long_rows,
+                                                        const int32_t* __restrict__ n_long, const int32_t* __restrict__ ip,
+                                                        const int32_t* __restrict__ ix, int32_t sect, uint32_t* __restrict__ keys) {
+    constexpr int ROUND = 4 * RK_AHEAD * 64;
+    __shared__ unsigned long long sh_rise[4 * RK_AHEAD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int count = n_long[1];
+    for (int li = blockIdx.x; li < count; li += gridDim.x) {
+        const int r = long_rows[nrow - 1 - li];
+        const int b = ip[r], e = ip[r + 1];
+        int best = 0, score = 0, best_at = -1;      // best_at: the entry whose rise set the best
+        for (int q0 = b; q0 < e; q0 += ROUND) {
+            int sec[RK_AHEAD], before[RK_AHEAD];
+#pragma unroll
+            for (int j = 0; j < RK_AHEAD; j++) {
+                const int p = q0 + (w * RK_AHEAD + j) * 64 + lane;
+                sec[j] = p < e ? ix[p] : 0;
+                before[j] = p < e && p > b ? ix[p - 1] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < RK_AHEAD; j++) {
+                const int p = q0 + (w * RK_AHEAD + j) * 64 + lane;
+                const unsigned long long rise = __ballot(p < e && sec[j] / sect > (p > b ? before[j] / sect : 0));
+                if (lane == 0) sh_rise[w * RK_AHEAD + j] = rise;
+            }
+            __syncthreads();
+            for (int c = 0; c < 4 * RK_AHEAD; c++) {
+                const int p0 = q0 + c * 64;
+                if (p0 >= e) break;
+                const unsigned long long rise = sh_rise[c];
+                const int nvalid = e - p0 < 64 ? e - p0 : 64;
+                int off = score;                     // the score at a rise at lane `at` is off + at
+                for (;;) {
+                    const int lo = best - off + 1 > 0 ? best - off + 1 : 0;
+                    if (lo >= 64) break;
+                    const unsigned long long m = rise & (~0ull << lo);
+                    if (!m) break;
+                    const int at = __ffsll(m) - 1;
+                    best = off + at;
+                    best_at = p0 + at;
+                    off = -at;
+                }
+                score = off + nvalid;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) keys[r] = (uint32_t)((best_at >= 0 ? ix[best_at - 1] / sect : -1) + 1);
     }
 }
 
@@ -868,25 +926,49 @@ __global__ void k_seq_offset(int32_t bnum, const int32_t* __restrict__ bnnz, con
 // range.  A block of more than RN_CAP elements raises `unfit` (the caller then runs the whole-stream form above).
 constexpr int RN_THREADS = 1024, RN_WAVES = RN_THREADS / 64, RN_PER = 4, RN_TILE = RN_THREADS * RN_PER, RN_CAP = 1 << 19;
 
+// one search per wave for the block of its first position (wave-uniform, so scalar loads); the lanes follow from it
 __global__ void k_block_col_keys(int64_t n, const int32_t* __restrict__ stream, const int32_t* __restrict__ bnnz, int32_t bnum,
                                  int col_bits, uint32_t* __restrict__ keys) {
     GRID_STRIDE(p, n) {
-        const int b = last_le(bnnz, bnum + 1, (int)p);
+        const int first = __builtin_amdgcn_readfirstlane((int)p);
+        int b = last_le(bnnz, bnum + 1, first);
+        while (bnnz[b + 1] <= (int)p) b++;      // bnnz[bnum] = n > p
         keys[p] = ((uint32_t)b << col_bits) | (uint32_t)stream[p];
     }
 }
 
-// counts[b] = columns of block b = runs of equal keys in its range of the sorted stream
-__global__ void __launch_bounds__(256) k_block_head_counts(const uint32_t* __restrict__ cs, const int32_t* __restrict__ bnnz,
+// counts[b] = columns of block b = runs of equal keys in its range of the sorted stream; counts must be zero.  The
+// block is the key's high part.  A wave walks HC_STEPS * 64 consecutive elements and adds once per block it meets
+// (an atomic per 64 elements, all on the few blocks at hand, cost more than the rest of the kernel).
+constexpr int HC_STEPS = 32;
+__global__ void __launch_bounds__(256) k_block_head_counts(int64_t n, const uint32_t* __restrict__ cs, int col_bits,
                                                            int32_t* __restrict__ counts) {
-    __shared__ int32_t tmp[4];
-    const int b = blockIdx.x, e0 = bnnz[b], e1 = bnnz[b + 1];
-    int c = 0;
-    for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) c += (i == e0 || cs[i - 1] != cs[i]) ? 1 : 0;
-    c = wave_reduce_sum(c);
-    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[b] = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    const int lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * HC_STEPS);
+    uint32_t cur = 0xffffffffu;     // block of the running sum
+    int acc = 0;
+    for (int st = 0; st < HC_STEPS; st++) {
+        const int64_t i0 = base + st * 64;
+        if (i0 >= n) break;
+        const int64_t i = i0 + lane;
+        const bool v = i < n;
+        const uint32_t k = v ? cs[i] : 0u;
+        const bool head = v && (i == 0 || cs[i - 1] != k);
+        const uint32_t b = col_bits >= 32 ? 0u : k >> col_bits;
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);       // lane 0 is valid: i0 < n
+        const bool same = __all(!v || b == b0);
+        if (!same || b0 != cur) {
+            if (lane == 0 && acc > 0) atomicAdd(&counts[cur], acc);
+            acc = 0;
+            cur = b0;
+        }
+        if (same) acc += __popcll(__ballot(head));
+        else {
+            if (head) atomicAdd(&counts[b], 1);
+            cur = 0xffffffffu;
+        }
+    }
+    if (lane == 0 && acc > 0) atomicAdd(&counts[cur], acc);
 }
 
 __global__ void __launch_bounds__(RN_THREADS) k_renumber_block(const uint32_t* __restrict__ cs, const uint32_t* __restrict__ psd,
@@ -1010,10 +1092,11 @@ int dev_row_keys(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, uint32_t* keys)
     int32_t *long_rows, *n_long;
     CHK(ws(ctx, WS_MISC1, (size_t)n + 1, &long_rows));
     CHK(ws(ctx, WS_COUNTERS, 64, &n_long));
-    HIPCHK(hipMemsetAsync(n_long, 0, sizeof(int32_t), ctx->stream));
+    HIPCHK(hipMemsetAsync(n_long, 0, 2 * sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, n, A->indptr, A->indices, sect, keys,
                        long_rows, n_long);
     hipLaunchKernelGGL(k_row_keys_long, dim3(1024), dim3(256), 0, ctx->stream, long_rows, n_long, A->indptr, A->indices, sect, keys);
+    hipLaunchKernelGGL(k_row_keys_giant, dim3(2048), dim3(256), 0, ctx->stream, n, long_rows, n_long, A->indptr, A->indices, sect, keys);
     return SPMM_OK;
 }
 
@@ -1229,7 +1312,9 @@ int dev_first_touch(spmm_ctx* ctx, int32_t ncol, int32_t nnz, int32_t bnum, cons
         hipLaunchKernelGGL(k_block_col_keys, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, stream, bnnz, bnum, col_bits, k0);
         hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)nnz);
         CHK(dev_radix_sort_pairs(ctx, k0, v0, cs, psd, nnz, col_bits + blk_bits));
-        hipLaunchKernelGGL(k_block_head_counts, dim3(bnum), dim3(256), 0, ctx->stream, cs, bnnz, counts);
+        HIPCHK(hipMemsetAsync(counts, 0, sizeof(int32_t) * ((size_t)bnum + 1), ctx->stream));
+        hipLaunchKernelGGL(k_block_head_counts, dim3((unsigned)(((int64_t)nnz + 256 * HC_STEPS - 1) / (256 * HC_STEPS))), dim3(256), 0, ctx->stream,
+                           (int64_t)nnz, cs, col_bits, counts);
         CHK(dev_exclusive_scan_i32(ctx, counts, seq_offset, bnum));     // seq_offset[bnum] = number of keys
         const uint32_t col_mask = col_bits >= 32 ? 0xffffffffu : (1u << col_bits) - 1u;
         hipLaunchKernelGGL(k_renumber_block, dim3(bnum), dim3(RN_THREADS), 0, ctx->stream, cs, psd, bnnz, seq_offset, col_mask, local, keys,
