@@ -465,6 +465,14 @@ __global__ void __launch_bounds__(256) k_block_sweep(int32_t nrow, int32_t nnz, 
     int x = 0, cnt = 0;         // the window [start of the row at hand, x) holds cnt new columns
     int ns = -1;                // first row start at or after the x it was looked up for
     bool started = false, ended = false;
+    // A row's step looks at the pairs of the row that leaves, at the elements at x and at the bitmap of row starts:
+    // three dependent trips to memory per row when each is loaded where it is needed.  Each lives in a register
+    // instead, 64 entries at a time, and is loaded again only when the sweep has moved past it: the pairs and the
+    // elements at x last about four rows of average length, the bitmap words 2048 elements.
+    int cw = -128, xa = -128, wb = -128;            // first entry of each cache (none yet)
+    int2 row_c = make_int2(0, 0);                   // pn[cw + lane]
+    int x_c = 0;                                    // pn[xa + lane].x
+    uint32_t bits_c = 0u;                           // rs_bits[wb + lane]
     for (int r = ra; r < rb; r++) {
         const int s = r_ip[r], e = r_ip[r + 1];
         if (e == s) continue;
@@ -477,12 +485,21 @@ __global__ void __launch_bounds__(256) k_block_sweep(int32_t nrow, int32_t nnz, 
             cnt = 0;
             started = true;
         } else {
-            int gone = 0, back = 0;
-            for (int q0 = ps; q0 < s; q0 += 64) {
+            if (ps < cw || ps >= cw + 64) {
+                cw = ps;
+                row_c = pn[ps + lane < nnz ? ps + lane : nnz - 1];
+            }
+            int gone, back;
+            {
+                const int q = cw + lane;
+                const bool v = q >= ps && q < s;
+                gone = __popcll(__ballot(v && row_c.x < ps));
+                back = __popcll(__ballot(v && row_c.y >= s && row_c.y < x));
+            }
+            for (int q0 = cw + 64; q0 < s; q0 += 64) {      // the rest of a row that runs past the cache
                 const int q = q0 + lane;
                 const bool v = q < s;
-                int2 a = make_int2(INT_MAX, INT_MAX);
-                if (v) a = pn[q];
+                const int2 a = pn[v ? q : nnz - 1];
                 gone += __popcll(__ballot(v && a.x < ps));
                 back += __popcll(__ballot(v && a.y >= s && a.y < x));
             }
@@ -500,36 +517,51 @@ __global__ void __launch_bounds__(256) k_block_sweep(int32_t nrow, int32_t nnz, 
                 x += 64 * SW_AHEAD;
                 continue;
             }
-            const int q = x + lane;
-            const bool f = q < nnz && pn[q].x < s;
+            if (x < xa || x >= xa + 64) {
+                xa = x;
+                x_c = pn[x + lane < nnz ? x + lane : nnz - 1].x;
+            }
+            const int q = xa + lane;
+            const bool f = q >= x && q < nnz && x_c < s;
             const unsigned long long b = __ballot(f);
             const int c = __popcll(b);
             if (cnt + c < threshold) {
                 cnt += c;
-                x = x + 64 < nnz ? x + 64 : nnz;
-            } else {            // the deciding element is the (threshold - cnt)-th new one of these 64
+                x = xa + 64 < nnz ? xa + 64 : nnz;
+            } else {            // the deciding element is the (threshold - cnt)-th new one of these
                 const int k = threshold - cnt;
                 const unsigned long long hit = __ballot(f && __popcll(b & le) == k);
-                x += __ffsll(hit);          // one past the deciding element
+                x = xa + __ffsll(hit);      // one past the deciding element
                 cnt = threshold;
             }
         }
         if (cnt >= threshold) {
-            // next row start after the deciding element x - 1; the answer of the row before holds while x stays below it
+            // The next block starts at the first row start after the deciding element x - 1: the next set bit of the
+            // row-start bitmap at or after x.  The answer of the row before holds while x stays below it.
             if (x > ns) {
-                const int p0 = x;
+                int w = x >> 5;
+                uint32_t first_mask = ~0u << (x & 31);          // for word w only
+                if (w < wb || w >= wb + 64) {
+                    wb = w;
+                    bits_c = rs_bits[w + lane];                 // the bitmap ends with 64 words of zeros
+                }
                 int found = nnz;
-                for (int w0 = p0 >> 5; (long long)w0 * 32 < (long long)nnz; w0 += 64) {
-                    const int wi = w0 + lane;
-                    uint32_t bits = (long long)wi * 32 < (long long)nnz ? rs_bits[wi] : 0u;
-                    if (wi == (p0 >> 5)) bits &= ~0u << (p0 & 31);
-                    const unsigned long long m = __ballot(bits != 0u);
+                for (;;) {
+                    uint32_t word = bits_c;
+                    if (wb + lane < w) word = 0u;
+                    if (wb + lane == w) word &= first_mask;
+                    const unsigned long long m = __ballot(word != 0u);
                     if (m) {
                         const int fl = __ffsll(m) - 1;
-                        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)bits, fl);
-                        found = (w0 + fl) * 32 + (__ffs(bw) - 1);
+                        const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)word, fl);
+                        found = (wb + fl) * 32 + (__ffs(bw) - 1);
                         break;
                     }
+                    if ((long long)(wb + 64) * 32 >= (long long)nnz) break;      // no row starts after x
+                    wb += 64;                                   // a row of more than 2048 entries: keep looking
+                    w = wb;
+                    first_mask = ~0u;
+                    bits_c = rs_bits[wb + lane];
                 }
                 ns = found < nnz ? found : nnz;
             }
