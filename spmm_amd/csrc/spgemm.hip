@@ -957,7 +957,11 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
     if (bins.n_t > 0) {    // the front of the list, several rows per wave
         constexpr int R = 64 / ESC_T_LANES;
         for_row_slices(ctx, bins.n_t, 64, R, [&](long long off, long long cnt) {
-            hipLaunchKernelGGL((k_esc_rows<ESC_T_LANES, ESC_T_CAP, NUMERIC>), dim3((unsigned)((cnt + R - 1) / R)), dim3(64), 0, ctx->stream,
+            // column ids of up to 26 bits leave room for the product number in the sorted word: sort in registers
+            constexpr bool can_pack = ESC_T_LANES == 8 && ESC_T_CAP == 64;
+            auto kt = can_pack && B->ncol <= (1 << 26) ? k_esc_rows<ESC_T_LANES, ESC_T_CAP, NUMERIC, can_pack>
+                                                       : k_esc_rows<ESC_T_LANES, ESC_T_CAP, NUMERIC, false>;
+            hipLaunchKernelGGL(kt, dim3((unsigned)((cnt + R - 1) / R)), dim3(64), 0, ctx->stream,
                                bins.list_s + off, (int)cnt, A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip,
                                row_beg, c_ix, c_val);
         });

@@ -93,6 +93,57 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
                                    c_ix, c_val);
 }
 
+// Sort of 64 packed keys held by 8 neighbouring lanes, 8 consecutive ranks per lane, ascending, without LDS: a bitonic
+// sorter in its all-ascending form (a block of k elements first meets its mirror image, e with e ^ (k - 1), then the
+// usual halvings), so that every exchange keeps the smaller key on the lower side.  Exchanges inside a lane are
+// min/max pairs on registers; those across lanes are DPP moves inside the group of 8 (quad permutations, the mirror
+// image of half a row).  An exchange in LDS costs two reads and up to four writes on the pipeline that all waves of a
+// CU share; the network in LDS was most of a tiny row's time.
+#define ESC_CE(a, b) { const uint32_t lo_ = (a) < (b) ? (a) : (b); (b) = (a) < (b) ? (b) : (a); (a) = lo_; }
+template <int CTRL>
+__device__ __forceinline__ uint32_t esc_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// partner = the same register of another lane (REV: the mirrored register); lower: this lane keeps the smaller keys
+template <int CTRL, bool REV>
+__device__ __forceinline__ void esc_cross(uint32_t (&r)[8], bool lower) {
+    uint32_t p[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = esc_dpp<CTRL>(r[REV ? 7 - i : i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t mn = r[i] < p[i] ? r[i] : p[i], mx = r[i] < p[i] ? p[i] : r[i];
+        r[i] = lower ? mn : mx;
+    }
+}
+__device__ __forceinline__ void esc_halve_in_lane(uint32_t (&r)[8]) {      // strides 4, 2, 1
+    ESC_CE(r[0], r[4]) ESC_CE(r[1], r[5]) ESC_CE(r[2], r[6]) ESC_CE(r[3], r[7])
+    ESC_CE(r[0], r[2]) ESC_CE(r[1], r[3]) ESC_CE(r[4], r[6]) ESC_CE(r[5], r[7])
+    ESC_CE(r[0], r[1]) ESC_CE(r[2], r[3]) ESC_CE(r[4], r[5]) ESC_CE(r[6], r[7])
+}
+__device__ __forceinline__ void esc_sort64_by_8_lanes(uint32_t (&r)[8], int l8) {
+    constexpr int QP_X1 = 0xB1, QP_X2 = 0x4E, QP_X3 = 0x1B, HALF_MIRROR = 0x141;   // lane ^ 1, ^ 2, ^ 3, ^ 7
+    // blocks of 2, 4 and 8: inside the lane
+    ESC_CE(r[0], r[1]) ESC_CE(r[2], r[3]) ESC_CE(r[4], r[5]) ESC_CE(r[6], r[7])
+    ESC_CE(r[0], r[3]) ESC_CE(r[1], r[2]) ESC_CE(r[4], r[7]) ESC_CE(r[5], r[6])
+    ESC_CE(r[0], r[1]) ESC_CE(r[2], r[3]) ESC_CE(r[4], r[5]) ESC_CE(r[6], r[7])
+    ESC_CE(r[0], r[7]) ESC_CE(r[1], r[6]) ESC_CE(r[2], r[5]) ESC_CE(r[3], r[4])
+    ESC_CE(r[0], r[2]) ESC_CE(r[1], r[3]) ESC_CE(r[4], r[6]) ESC_CE(r[5], r[7])
+    ESC_CE(r[0], r[1]) ESC_CE(r[2], r[3]) ESC_CE(r[4], r[5]) ESC_CE(r[6], r[7])
+    // blocks of 16: two lanes
+    esc_cross<QP_X1, true>(r, (l8 & 1) == 0);
+    esc_halve_in_lane(r);
+    // blocks of 32: four lanes
+    esc_cross<QP_X3, true>(r, (l8 & 2) == 0);
+    esc_cross<QP_X1, false>(r, (l8 & 1) == 0);
+    esc_halve_in_lane(r);
+    // the block of 64: eight lanes
+    esc_cross<HALF_MIRROR, true>(r, (l8 & 4) == 0);
+    esc_cross<QP_X2, false>(r, (l8 & 2) == 0);
+    esc_cross<QP_X1, false>(r, (l8 & 1) == 0);
+    esc_halve_in_lane(r);
+}
+
 // The tiny rows of the smallest bin, 64/L per 64-lane workgroup.  Such a row is a chain of five dependent gathers
 // of a few dozen bytes each (list, row pointers of A, entries of A, row pointers of B, entries of B): latency, not
 // bandwidth, is its cost, so a row of at most QC products is expanded, sorted and compressed by L lanes in its
@@ -100,7 +151,10 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
 // entries' ascending runs by rank, a binary search per product and other run, instead of the sorting network: the
 // searches are chains of dependent LDS reads, the network's stages are not; 0.43 + 0.82 -> 0.55 + 0.89 ms on a
 // web-Google-sized graph.)
-template <int L, int QC, bool NUMERIC>
+// PACK (8 lanes, 64 products, column ids below 2^26): the products are sorted in registers as (column << 6 | product
+// number) words, esc_sort64_by_8_lanes; the product number keeps equal columns in product order and finds the value.
+// The keys' LDS rows are padded by one word in eight so that a lane's eight consecutive words miss each other's banks.
+template <int L, int QC, bool NUMERIC, bool PACK = false>
 __global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ list, const int n_list, const int32_t* __restrict__ a_ip,
                                              const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                              const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
@@ -108,9 +162,12 @@ __global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ lis
                                              int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
     static_assert(L == 8 || L == 16 || L == 32, "lanes per row");
     static_assert(QC % L == 0, "whole rounds of products");
+    static_assert(!PACK || (L == 8 && QC == 64), "the register sort is written for 8 lanes of 8 keys");
     constexpr int R = 64 / L;             // rows per wave
     constexpr int CAP = R * QC;
-    __shared__ int32_t skey[CAP];
+    constexpr int QS = PACK ? QC + QC / 8 : QC;       // words per row of keys
+    auto pad = [](int e) { return PACK ? e + (e >> 3) : e; };
+    __shared__ int32_t skey[R * QS];
     __shared__ double sval[NUMERIC ? CAP : 1];
     __shared__ int32_t eoff[R][L], eb0[R][L];
     __shared__ double eav[NUMERIC ? R : 1][L];
@@ -125,7 +182,7 @@ __global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ lis
         a1 = a_ip[row + 1];
         if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
     }
-    int32_t* qkey = skey + q * QC;
+    int32_t* qkey = skey + q * QS;
     double* qval = sval + (NUMERIC ? q * QC : 0);
     // expand: the L lanes of a row have the same trip count, and the shuffles stay among them
     int run = 0;
@@ -162,12 +219,50 @@ __global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ lis
                 for (int h = L / 2; h > 0; h >>= 1)
                     if (eoff[q][e + h] <= j) e += h;       // the last entry that starts at or before product j
                 const int src = eb0[q][e] + (j - eoff[q][e]);
-                qkey[run + j] = b_ix[src];
+                qkey[pad(run + j)] = b_ix[src];
                 if (NUMERIC) qval[run + j] = eav[NUMERIC ? q : 0][e] * b_val[src];
             }
         }
         __builtin_amdgcn_wave_barrier();
         run += tot;
+    }
+    if constexpr (PACK) {
+        wave_sync_lds();
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int e = ql * 8 + i;
+            r[i] = e < run ? ((uint32_t)qkey[pad(e)] << 6) | (uint32_t)e : 0xffffffffu;
+        }
+        wave_sync_lds();            // every lane has its keys before the sorted ones are written over them
+        esc_sort64_by_8_lanes(r, ql);
+#pragma unroll
+        for (int i = 0; i < 8; i++) qkey[pad(ql * 8 + i)] = (int32_t)r[i];
+        wave_sync_lds();
+        int runmax = run;
+#pragma unroll
+        for (int d = L; d < 64; d <<= 1) runmax = max(runmax, __shfl_xor(runmax, d));
+        int outrun = 0;
+        for (int c0 = 0; c0 < runmax; c0 += L) {
+            const int t = c0 + ql;
+            const uint32_t pk = t < run ? (uint32_t)qkey[pad(t)] : 0xffffffffu;
+            const bool head = t < run && (t == 0 || ((uint32_t)qkey[pad(t - 1)] >> 6) != (pk >> 6));
+            const unsigned m = (unsigned)((__ballot(head) >> (q * L)) & ((1ull << L) - 1ull));
+            const int o = outrun + __popc(m & ((1u << ql) - 1u));
+            if (NUMERIC && head) {
+                double sum = qval[pk & 63u];
+                for (int u = t + 1; u < run; u++) {
+                    const uint32_t pu = (uint32_t)qkey[pad(u)];
+                    if ((pu >> 6) != (pk >> 6)) break;
+                    sum += qval[pu & 63u];
+                }
+                c_ix[obase + o] = (int32_t)(pk >> 6);
+                c_val[obase + o] = sum;
+            }
+            outrun += __popc(m);
+        }
+        if (!NUMERIC && small && ql == 0) rowcnt[row] = outrun;
+        return;
     }
     int n2 = 0;
     if (small) {
