@@ -950,7 +950,9 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
     }
     if (bins.n_s > 0)      // the back of the list
         for_row_slices(ctx, bins.n_s, 64, 1, [&](long long off, long long cnt) {
-            hipLaunchKernelGGL((k_esc<64, ESC_S_CAP, NUMERIC>), dim3((unsigned)cnt), dim3(64), 0, ctx->stream,
+            // column ids of up to 23 bits leave room for the product number in the sorted word: sort in registers
+            hipLaunchKernelGGL((B->ncol <= (1 << 23) ? k_esc<64, ESC_S_CAP, NUMERIC, true> : k_esc<64, ESC_S_CAP, NUMERIC, false>),
+                               dim3((unsigned)cnt), dim3(64), 0, ctx->stream,
                                bins.list_s + ((size_t)A->nrow + 1 - (size_t)bins.n_s) + off, A->indptr, A->indices, A->data, B->indptr,
                                B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
         });

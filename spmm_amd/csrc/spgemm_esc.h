@@ -6,93 +6,6 @@
 
 namespace {
 
-// ---------------------------------------------------------------------------
-// Expand / sort / compress in LDS, one row by the whole workgroup.
-template <int THREADS, int CAP, bool NUMERIC>
-__device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sval, int32_t* tmp,
-                                        const int32_t* __restrict__ a_ip,
-                                        const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                        const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
-                                        const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
-                                        const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                        int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
-    const int tid = threadIdx.x;
-    const int a0 = a_ip[row], a1 = a_ip[row + 1];
-    int64_t obase = 0;
-    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
-
-    int run = 0;
-    for (int e0 = a0; e0 < a1; e0 += THREADS) {
-        int p = e0 + tid, len = 0, b0 = 0;
-        double av = 0.0;
-        if (p < a1) {
-            int k = a_ix[p];
-            b0 = b_ip[k];
-            len = b_ip[k + 1] - b0;
-            if (NUMERIC) av = a_val[p];
-        }
-        int tot;
-        int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;
-        for (int q = 0; q < len; q++) {
-            skey[off + q] = b_ix[b0 + q];
-            if (NUMERIC) sval[off + q] = av * b_val[b0 + q];
-        }
-        run += tot;
-    }
-    int n2 = 1;
-    while (n2 < run) n2 <<= 1;
-    for (int i = run + tid; i < n2; i += THREADS) skey[i] = KEY_PAD;
-    __syncthreads();
-
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += THREADS) {
-                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                int l = i | j;
-                bool up = (i & k) == 0;
-                int ki = skey[i], kl = skey[l];
-                if ((ki > kl) == up) {
-                    skey[i] = kl;
-                    skey[l] = ki;
-                    if (NUMERIC) { double x = sval[i]; sval[i] = sval[l]; sval[l] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    int outrun = 0;
-    for (int c0 = 0; c0 < n2; c0 += THREADS) {
-        int t = c0 + tid;
-        int key = t < n2 ? skey[t] : KEY_PAD;
-        bool head = key != KEY_PAD && (t == 0 || skey[t - 1] != key);
-        int tot;
-        int r = block_exclusive_scan<THREADS, int32_t>(head ? 1 : 0, tmp, &tot) + outrun;
-        if (NUMERIC && head) {
-            double s = sval[t];
-            for (int u = t + 1; u < n2 && skey[u] == key; u++) s += sval[u];
-            c_ix[obase + r] = key;
-            c_val[obase + r] = s;
-        }
-        outrun += tot;
-    }
-    if (!NUMERIC && tid == 0) rowcnt[row] = outrun;
-}
-
-template <int THREADS, int CAP, bool NUMERIC>
-__global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
-                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
-                                                 const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
-                                                 const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
-                                                 const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
-    __shared__ int32_t skey[CAP];
-    __shared__ double sval[NUMERIC ? CAP : 1];
-    __shared__ int32_t tmp[THREADS / 64 + 1];
-    esc_row<THREADS, CAP, NUMERIC>(list[blockIdx.x], skey, sval, tmp, a_ip, a_ix, a_val, b_ip, b_ix, b_val, rowcnt, c_ip, row_beg,
-                                   c_ix, c_val);
-}
-
 // Sort of 64 packed keys held by 8 neighbouring lanes, 8 consecutive ranks per lane, ascending, without LDS: a bitonic
 // sorter in its all-ascending form (a block of k elements first meets its mirror image, e with e ^ (k - 1), then the
 // usual halvings), so that every exchange keeps the smaller key on the lower side.  Exchanges inside a lane are
@@ -142,6 +55,209 @@ __device__ __forceinline__ void esc_sort64_by_8_lanes(uint32_t (&r)[8], int l8) 
     esc_cross<QP_X2, false>(r, (l8 & 2) == 0);
     esc_cross<QP_X1, false>(r, (l8 & 1) == 0);
     esc_halve_in_lane(r);
+}
+
+// The same for a whole wave: 64 * P packed keys, P consecutive ranks per lane (P = 2, 4 or 8).  Lanes further apart
+// than a DPP move reaches (lane ^ 4, ^ 16, ^ 31, ^ 32, ^ 63) exchange through ds_bpermute.
+template <int MASK>
+__device__ __forceinline__ uint32_t esc_xlane(uint32_t v) {
+    if constexpr (MASK == 1) return esc_dpp<0xB1>(v);            // quad permutations
+    else if constexpr (MASK == 2) return esc_dpp<0x4E>(v);
+    else if constexpr (MASK == 3) return esc_dpp<0x1B>(v);
+    else if constexpr (MASK == 7) return esc_dpp<0x141>(v);      // mirror image of half a row
+    else if constexpr (MASK == 15) return esc_dpp<0x140>(v);     // mirror image of a row
+    else if constexpr (MASK == 8) return esc_dpp<0x128>(v);      // a row rotated by 8
+    else return (uint32_t)__shfl_xor((int)v, MASK, 64);
+}
+template <int P, int K>
+__device__ __forceinline__ void esc_lane_mirror(uint32_t (&r)[P]) {
+#pragma unroll
+    for (int b = 0; b < P; b += K)
+#pragma unroll
+        for (int i = 0; i < K / 2; i++) ESC_CE(r[b + i], r[b + K - 1 - i])
+}
+template <int P, int J0>
+__device__ __forceinline__ void esc_lane_halve(uint32_t (&r)[P]) {
+#pragma unroll
+    for (int j = J0; j >= 1; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if ((i & j) == 0) ESC_CE(r[i], r[i | j])
+}
+template <int P, int MASK, bool REV>
+__device__ __forceinline__ void esc_wave_cross(uint32_t (&r)[P], bool lower) {
+    uint32_t p[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) p[i] = esc_xlane<MASK>(r[REV ? P - 1 - i : i]);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const uint32_t mn = r[i] < p[i] ? r[i] : p[i], mx = r[i] < p[i] ? p[i] : r[i];
+        r[i] = lower ? mn : mx;
+    }
+}
+template <int P, int J>
+__device__ __forceinline__ void esc_wave_steps(uint32_t (&r)[P], int lane) {      // strides J, J / 2, ... P
+    esc_wave_cross<P, J / P, false>(r, (lane & (J / P)) == 0);
+    if constexpr (J / 2 >= P) esc_wave_steps<P, J / 2>(r, lane);
+}
+template <int P, int K>
+__device__ __forceinline__ void esc_wave_merge(uint32_t (&r)[P], int lane) {      // blocks of K > P elements
+    esc_wave_cross<P, K / P - 1, true>(r, (lane & (K / (2 * P))) == 0);
+    if constexpr (K / 4 >= P) esc_wave_steps<P, K / 4>(r, lane);
+    esc_lane_halve<P, P / 2>(r);
+}
+template <int P>
+__device__ __forceinline__ void esc_sort_wave(uint32_t (&r)[P], int lane) {
+    static_assert(P == 2 || P == 4 || P == 8, "keys per lane");
+    esc_lane_mirror<P, 2>(r);
+    if constexpr (P >= 4) { esc_lane_mirror<P, 4>(r); esc_lane_halve<P, 1>(r); }
+    if constexpr (P >= 8) { esc_lane_mirror<P, 8>(r); esc_lane_halve<P, 2>(r); }
+    esc_wave_merge<P, 2 * P>(r, lane);
+    esc_wave_merge<P, 4 * P>(r, lane);
+    esc_wave_merge<P, 8 * P>(r, lane);
+    esc_wave_merge<P, 16 * P>(r, lane);
+    esc_wave_merge<P, 32 * P>(r, lane);
+    esc_wave_merge<P, 64 * P>(r, lane);
+}
+// keys of one row from LDS (padded by one word in eight), sorted, and back
+template <int P>
+__device__ __forceinline__ void esc_sort_row_in_registers(int32_t* skey, int run, int tid) {
+    constexpr int SH = P == 2 ? 7 : P == 4 ? 8 : 9;          // bits of the product number
+    uint32_t r[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int e = tid * P + i;
+        r[i] = e < run ? ((uint32_t)skey[e + (e >> 3)] << SH) | (uint32_t)e : 0xffffffffu;
+    }
+    wave_sync_lds();
+    esc_sort_wave<P>(r, tid);
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int e = tid * P + i;
+        skey[e + (e >> 3)] = (int32_t)r[i];
+    }
+    wave_sync_lds();
+}
+
+// ---------------------------------------------------------------------------
+// Expand / sort / compress in LDS, one row by the whole workgroup.
+// PACK (one wave, column ids of at most 23 bits): the keys are sorted in registers as (column << s | product number)
+// words, esc_sort_wave over 2, 4 or 8 keys per lane by the row's products; the product number keeps equal columns in
+// product order and finds the value.
+template <int THREADS, int CAP, bool NUMERIC, bool PACK = false>
+__device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sval, int32_t* tmp,
+                                        const int32_t* __restrict__ a_ip,
+                                        const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                        const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                        const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                        const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                        int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    const int tid = threadIdx.x;
+    const int a0 = a_ip[row], a1 = a_ip[row + 1];
+    int64_t obase = 0;
+    if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
+
+    int run = 0;
+    for (int e0 = a0; e0 < a1; e0 += THREADS) {
+        int p = e0 + tid, len = 0, b0 = 0;
+        double av = 0.0;
+        if (p < a1) {
+            int k = a_ix[p];
+            b0 = b_ip[k];
+            len = b_ip[k + 1] - b0;
+            if (NUMERIC) av = a_val[p];
+        }
+        int tot;
+        int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;
+        for (int q = 0; q < len; q++) {
+            skey[PACK ? off + q + ((off + q) >> 3) : off + q] = b_ix[b0 + q];
+            if (NUMERIC) sval[off + q] = av * b_val[b0 + q];
+        }
+        run += tot;
+    }
+    if constexpr (PACK) {
+        static_assert(THREADS == 64, "one wave");
+        wave_sync_lds();
+        int sh;
+        if (run <= 128) { esc_sort_row_in_registers<2>(skey, run, tid); sh = 7; }
+        else if (run <= 256) { esc_sort_row_in_registers<4>(skey, run, tid); sh = 8; }
+        else { esc_sort_row_in_registers<8>(skey, run, tid); sh = 9; }
+        const uint32_t low = (1u << sh) - 1u;
+        const unsigned long long lt = lanemask_lt();
+        int outrun = 0;
+        for (int c0 = 0; c0 < run; c0 += 64) {
+            const int t = c0 + tid;
+            const uint32_t pk = t < run ? (uint32_t)skey[t + (t >> 3)] : 0xffffffffu;
+            const bool head = t < run && (t == 0 || ((uint32_t)skey[t - 1 + ((t - 1) >> 3)] >> sh) != (pk >> sh));
+            const unsigned long long m = __ballot(head);
+            if (NUMERIC && head) {
+                const int o = outrun + __popcll(m & lt);
+                double sum = sval[pk & low];
+                for (int u = t + 1; u < run; u++) {
+                    const uint32_t pu = (uint32_t)skey[u + (u >> 3)];
+                    if ((pu >> sh) != (pk >> sh)) break;
+                    sum += sval[pu & low];
+                }
+                c_ix[obase + o] = (int32_t)(pk >> sh);
+                c_val[obase + o] = sum;
+            }
+            outrun += __popcll(m);
+        }
+        if (!NUMERIC && tid == 0) rowcnt[row] = outrun;
+        return;
+    }
+    int n2 = 1;
+    while (n2 < run) n2 <<= 1;
+    for (int i = run + tid; i < n2; i += THREADS) skey[i] = KEY_PAD;
+    __syncthreads();
+
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                bool up = (i & k) == 0;
+                int ki = skey[i], kl = skey[l];
+                if ((ki > kl) == up) {
+                    skey[i] = kl;
+                    skey[l] = ki;
+                    if (NUMERIC) { double x = sval[i]; sval[i] = sval[l]; sval[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    int outrun = 0;
+    for (int c0 = 0; c0 < n2; c0 += THREADS) {
+        int t = c0 + tid;
+        int key = t < n2 ? skey[t] : KEY_PAD;
+        bool head = key != KEY_PAD && (t == 0 || skey[t - 1] != key);
+        int tot;
+        int r = block_exclusive_scan<THREADS, int32_t>(head ? 1 : 0, tmp, &tot) + outrun;
+        if (NUMERIC && head) {
+            double s = sval[t];
+            for (int u = t + 1; u < n2 && skey[u] == key; u++) s += sval[u];
+            c_ix[obase + r] = key;
+            c_val[obase + r] = s;
+        }
+        outrun += tot;
+    }
+    if (!NUMERIC && tid == 0) rowcnt[row] = outrun;
+}
+
+template <int THREADS, int CAP, bool NUMERIC, bool PACK = false>
+__global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
+                                                 const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
+                                                 const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
+                                                 const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
+                                                 const int64_t* __restrict__ c_ip, int32_t row_beg,
+                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+    __shared__ int32_t skey[PACK ? CAP + CAP / 8 : CAP];
+    __shared__ double sval[NUMERIC ? CAP : 1];
+    __shared__ int32_t tmp[THREADS / 64 + 1];
+    esc_row<THREADS, CAP, NUMERIC, PACK>(list[blockIdx.x], skey, sval, tmp, a_ip, a_ix, a_val, b_ip, b_ix, b_val, rowcnt, c_ip, row_beg,
+                                   c_ix, c_val);
 }
 
 // The tiny rows of the smallest bin, 64/L per 64-lane workgroup.  Such a row is a chain of five dependent gathers
