@@ -158,22 +158,62 @@ __device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sv
     if (NUMERIC) obase = c_ip[row] - c_ip[row_beg];
 
     int run = 0;
-    for (int e0 = a0; e0 < a1; e0 += THREADS) {
-        int p = e0 + tid, len = 0, b0 = 0;
-        double av = 0.0;
-        if (p < a1) {
-            int k = a_ix[p];
-            b0 = b_ip[k];
-            len = b_ip[k + 1] - b0;
-            if (NUMERIC) av = a_val[p];
+    if constexpr (THREADS == 64) {
+        // One wave: the products of 64 entries as one index space dealt round the lanes, as in k_esc_rows (a lane that
+        // walks its own row of B alone pays one latency per product, and the longest row of B sets the time of all).
+        __shared__ int32_t eoff[64], eb0[64];
+        __shared__ double eav[NUMERIC ? 64 : 1];
+        for (int e0 = a0; e0 < a1; e0 += 64) {
+            const int p = e0 + tid;
+            int len = 0, b0 = 0;
+            double av = 0.0;
+            if (p < a1) {
+                const int k = a_ix[p];
+                b0 = b_ip[k];
+                len = b_ip[k + 1] - b0;
+                if (NUMERIC) av = a_val[p];
+            }
+            const int inc = wave_inclusive_scan_i32(len);
+            const int tot = __builtin_amdgcn_readlane(inc, 63);
+            eoff[tid] = inc - len;
+            eb0[tid] = b0;
+            if (NUMERIC) eav[NUMERIC ? tid : 0] = av;
+            wave_sync_lds();
+#pragma unroll
+            for (int i = 0; i < CAP / 64; i++) {
+                const int j = tid + 64 * i;
+                if (j < tot) {
+                    int e = 0;
+#pragma unroll
+                    for (int h = 32; h > 0; h >>= 1)
+                        if (eoff[e + h] <= j) e += h;          // the last entry that starts at or before product j
+                    const int src = eb0[e] + (j - eoff[e]);
+                    const int at = run + j;
+                    skey[PACK ? at + (at >> 3) : at] = b_ix[src];
+                    if (NUMERIC) sval[at] = eav[NUMERIC ? e : 0] * b_val[src];
+                }
+            }
+            wave_sync_lds();
+            run += tot;
         }
-        int tot;
-        int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;
-        for (int q = 0; q < len; q++) {
-            skey[PACK ? off + q + ((off + q) >> 3) : off + q] = b_ix[b0 + q];
-            if (NUMERIC) sval[off + q] = av * b_val[b0 + q];
+    } else {
+        for (int e0 = a0; e0 < a1; e0 += THREADS) {
+            int p = e0 + tid, len = 0, b0 = 0;
+            double av = 0.0;
+            if (p < a1) {
+                int k = a_ix[p];
+                b0 = b_ip[k];
+                len = b_ip[k + 1] - b0;
+                if (NUMERIC) av = a_val[p];
+            }
+            int tot;
+            int off = block_exclusive_scan<THREADS, int32_t>(len, tmp, &tot) + run;
+            for (int q = 0; q < len; q++) {
+                skey[off + q] = b_ix[b0 + q];
+                if (NUMERIC) sval[off + q] = av * b_val[b0 + q];
+            }
+            run += tot;
         }
-        run += tot;
     }
     if constexpr (PACK) {
         static_assert(THREADS == 64, "one wave");
