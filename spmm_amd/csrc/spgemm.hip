@@ -934,7 +934,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         for_row_slices(ctx, bins.n_m, RT, 1, [&](long long off, long long cnt) {
             hipLaunchKernelGGL(kr, dim3((unsigned)cnt), dim3(RT), rl, ctx->stream, bins.list_m + off, A->indptr, A->indices, A->data,
                                B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
-                               bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+                               bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u), (const int64_t*)nullptr, 0);
         });
     }
     if (bins.n_l > 0) {
@@ -942,10 +942,17 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
         static_assert(2 * rl <= 160 * 1024, "two workgroups per CU");
         auto kr = k_escr<512, ESC_L_CAP, NUMERIC>;
         HIPCHK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+        // Column ids of up to 22 bits: the rows of up to ESC_W_CAP products go to one wave each, sorted in registers (sixteen
+        // keys per lane), but for the few-entry rows that the radix kernel merges; both kernels walk the whole list.
+        const int one_wave_cap = B->ncol <= (1 << 22) ? ESC_W_CAP : 0;
         for_row_slices(ctx, bins.n_l, 512, 1, [&](long long off, long long cnt) {
+            if (one_wave_cap)
+                hipLaunchKernelGGL((k_esc<64, ESC_W_CAP, NUMERIC, true>), dim3((unsigned)cnt), dim3(64), 0, ctx->stream, bins.list_l + off,
+                                   A->indptr, A->indices, A->data, B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
+                                   (const int64_t*)bins.prod);
             hipLaunchKernelGGL(kr, dim3((unsigned)cnt), dim3(512), rl, ctx->stream, bins.list_l + off, A->indptr, A->indices, A->data,
                                B->indptr, B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val,
-                               bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u));
+                               bits_for(B->ncol > 0 ? (uint32_t)(B->ncol - 1) : 0u), (const int64_t*)bins.prod, one_wave_cap);
         });
     }
     if (bins.n_s > 0)      // the back of the list
@@ -954,7 +961,7 @@ int launch_rows(spmm_ctx* ctx, const spmm_csr* A, const spmm_csr* B, const Bins&
             hipLaunchKernelGGL((B->ncol <= (1 << 23) ? k_esc<64, ESC_S_CAP, NUMERIC, true> : k_esc<64, ESC_S_CAP, NUMERIC, false>),
                                dim3((unsigned)cnt), dim3(64), 0, ctx->stream,
                                bins.list_s + ((size_t)A->nrow + 1 - (size_t)bins.n_s) + off, A->indptr, A->indices, A->data, B->indptr,
-                               B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val);
+                               B->indices, B->data, rowcnt, c_ip, row_beg, c_ix, c_val, (const int64_t*)nullptr);
         });
     if (bins.n_t > 0) {    // the front of the list, several rows per wave
         constexpr int R = 64 / ESC_T_LANES;

@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int ESC_S_CAP = 512;
+constexpr int ESC_W_CAP = 1024;        // rows of the radix kernel's list with up to this many products: one wave, sorted in registers
 #ifndef ESC_T_CAP
 #define ESC_T_CAP 64       // rows of at most this many products go several to a wave,
 #endif

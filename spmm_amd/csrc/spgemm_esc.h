@@ -4,6 +4,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef ESC_MERGE_MAX
+#define ESC_MERGE_MAX 4     // rows of at most this many entries: their rows of B are merged by rank (k_escr)
+#endif
+
 namespace {
 
 // Sort of 64 packed keys held by 8 neighbouring lanes, 8 consecutive ranks per lane, ascending, without LDS: a bitonic
@@ -108,10 +112,11 @@ __device__ __forceinline__ void esc_wave_merge(uint32_t (&r)[P], int lane) {    
 }
 template <int P>
 __device__ __forceinline__ void esc_sort_wave(uint32_t (&r)[P], int lane) {
-    static_assert(P == 2 || P == 4 || P == 8, "keys per lane");
+    static_assert(P == 2 || P == 4 || P == 8 || P == 16, "keys per lane");
     esc_lane_mirror<P, 2>(r);
     if constexpr (P >= 4) { esc_lane_mirror<P, 4>(r); esc_lane_halve<P, 1>(r); }
     if constexpr (P >= 8) { esc_lane_mirror<P, 8>(r); esc_lane_halve<P, 2>(r); }
+    if constexpr (P >= 16) { esc_lane_mirror<P, 16>(r); esc_lane_halve<P, 4>(r); }
     esc_wave_merge<P, 2 * P>(r, lane);
     esc_wave_merge<P, 4 * P>(r, lane);
     esc_wave_merge<P, 8 * P>(r, lane);
@@ -122,7 +127,7 @@ __device__ __forceinline__ void esc_sort_wave(uint32_t (&r)[P], int lane) {
 // keys of one row from LDS (padded by one word in eight), sorted, and back
 template <int P>
 __device__ __forceinline__ void esc_sort_row_in_registers(int32_t* skey, int run, int tid) {
-    constexpr int SH = P == 2 ? 7 : P == 4 ? 8 : 9;          // bits of the product number
+    constexpr int SH = P == 2 ? 7 : P == 4 ? 8 : P == 8 ? 9 : 10;     // bits of the product number
     uint32_t r[P];
 #pragma unroll
     for (int i = 0; i < P; i++) {
@@ -141,8 +146,8 @@ __device__ __forceinline__ void esc_sort_row_in_registers(int32_t* skey, int run
 
 // ---------------------------------------------------------------------------
 // Expand / sort / compress in LDS, one row by the whole workgroup.
-// PACK (one wave, column ids of at most 23 bits): the keys are sorted in registers as (column << s | product number)
-// words, esc_sort_wave over 2, 4 or 8 keys per lane by the row's products; the product number keeps equal columns in
+// PACK (one wave; column ids of at most 23 bits, 22 with a CAP of 1024): the keys are sorted in registers as
+// (column << s | product number) words, esc_sort_wave over 2, 4, 8 or 16 keys per lane by the row's products; the product number keeps equal columns in
 // product order and finds the value.
 template <int THREADS, int CAP, bool NUMERIC, bool PACK = false>
 __device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sval, int32_t* tmp,
@@ -221,7 +226,8 @@ __device__ __forceinline__ void esc_row(const int row, int32_t* skey, double* sv
         int sh;
         if (run <= 128) { esc_sort_row_in_registers<2>(skey, run, tid); sh = 7; }
         else if (run <= 256) { esc_sort_row_in_registers<4>(skey, run, tid); sh = 8; }
-        else { esc_sort_row_in_registers<8>(skey, run, tid); sh = 9; }
+        else if (CAP <= 512 || run <= 512) { esc_sort_row_in_registers<8>(skey, run, tid); sh = 9; }
+        else { esc_sort_row_in_registers<16>(skey, run, tid); sh = 10; }
         const uint32_t low = (1u << sh) - 1u;
         const unsigned long long lt = lanemask_lt();
         int outrun = 0;
@@ -292,10 +298,15 @@ __global__ void __launch_bounds__(THREADS) k_esc(const int32_t* __restrict__ lis
                                                  const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
                                                  const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
                                                  const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val) {
+                                                 int32_t* __restrict__ c_ix, double* __restrict__ c_val,
+                                                 const int64_t* __restrict__ prod) {
     __shared__ int32_t skey[PACK ? CAP + CAP / 8 : CAP];
     __shared__ double sval[NUMERIC ? CAP : 1];
     __shared__ int32_t tmp[THREADS / 64 + 1];
+    if (prod != nullptr) {      // over the list of the radix kernel: its rows of up to CAP products, but for the few-entry rows it merges
+        const int row = list[blockIdx.x];
+        if (prod[row] > CAP || a_ip[row + 1] - a_ip[row] <= ESC_MERGE_MAX) return;
+    }
     esc_row<THREADS, CAP, NUMERIC, PACK>(list[blockIdx.x], skey, sval, tmp, a_ip, a_ix, a_val, b_ip, b_ix, b_val, rowcnt, c_ip, row_beg,
                                    c_ix, c_val);
 }
@@ -475,16 +486,14 @@ __global__ void __launch_bounds__(64) k_esc_rows(const int32_t* __restrict__ lis
 // workgroup: one scan over [digit][wave]); equal columns end adjacent.  Values are not carried
 // through the sort: the compress step reads a*b through the sorted index (position in B and entry
 // of A per product).
-#ifndef ESC_MERGE_MAX
-#define ESC_MERGE_MAX 4
-#endif
 template <int THREADS, int CAP, bool NUMERIC>
 __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ list, const int32_t* __restrict__ a_ip,
                                                   const int32_t* __restrict__ a_ix, const double* __restrict__ a_val,
                                                   const int32_t* __restrict__ b_ip, const int32_t* __restrict__ b_ix,
                                                   const double* __restrict__ b_val, int32_t* __restrict__ rowcnt,
                                                   const int64_t* __restrict__ c_ip, int32_t row_beg,
-                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val, int key_bits) {
+                                                  int32_t* __restrict__ c_ix, double* __restrict__ c_val, int key_bits,
+                                                  const int64_t* __restrict__ prod, int one_wave_cap) {
     constexpr int NW = THREADS / 64;
     constexpr int EPT = CAP / THREADS;        // elements per thread
     constexpr int CPW = CAP / NW;             // elements per wave in a sort pass
@@ -505,6 +514,8 @@ __global__ void __launch_bounds__(THREADS) k_escr(const int32_t* __restrict__ li
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row = list[blockIdx.x];
     const int a0 = a_ip[row], lenA = a_ip[row + 1] - a0;
+    // rows of up to one_wave_cap products and more than ESC_MERGE_MAX entries were sorted by one wave in registers (k_esc)
+    if (one_wave_cap > 0 && prod[row] <= one_wave_cap && lenA > ESC_MERGE_MAX) return;
 
     // A row with one entry is that row of B times a number: ascending columns already, and distinct ones
     // unless the row of B repeats a column (rows of B may: the loader keeps duplicates).
