@@ -2,11 +2,11 @@
 // as data-parallel HIP kernels for gfx950.  Stage by stage:
 //
 //   row keys + stable bucket + row gather   bitmap.h:108-170        k_row_keys, radix sort, gather
-//   greedy row blocking                     transmat.h:334-376      prev-occurrence + k_block_chain
+//   greedy row blocking                     transmat.h:334-376      (prev, next) occurrence + k_block_sweep + k_block_walk
 //   panel boundaries                        v8sort.h:49-73          k_panel_list (prefix-min form)
 //   per-panel order + 8-row grouping        v8sort.h:152-232        k_panel_sort: one workgroup per panel, in LDS
 //   block row gather + 8-row interleave     serial_newblock_clock.cpp:336-399   gather (fused)
-//   first-touch column renumbering          serial_newblock_clock.cpp:187-204   sort by (col,pos)
+//   first-touch column renumbering          serial_newblock_clock.cpp:187-204   sort by (block,col,pos), k_renumber_block
 //   write-back / fetch sequence             wbsort.h:16-95          compose / invert / gather
 //
 // Tie rule of the panel sort: stable by (length, block-local row id).  The reference's
@@ -274,6 +274,7 @@ __global__ void k_prev_next_from_sorted(int64_t n, const uint32_t* __restrict__ 
 // chain.  BC_TILES workgroups count the new columns of 8192 elements each from the current
 // position; the workgroup that finishes last adds the tile counts, finds the deciding tile and
 // element, cuts, and moves the state on.  Steps after the end of the stream do nothing.
+// (This form runs with SPMM_CHAIN_SWEEP=0, as the cross-check of the sweep further down, which is the default.)
 constexpr int BC_THREADS = 1024, BC_ITEMS = 8, BC_TILE = BC_THREADS * BC_ITEMS, BC_TILES = 64;
 struct bc_state {
     int32_t s0, pos, cnt, nb, done, overflow, ticket, pad;

@@ -5,13 +5,18 @@
 //
 // Rows are binned by their number of intermediate products P_i = sum_k len_B(k):
 //   P_i == 0                 nothing to do
-//   P_i <= ESC_T_CAP (64)    k_esc_rows: the same expand / bitonic sort / sum by 8 lanes, so a 64-lane
+//   P_i <= ESC_T_CAP (64)    k_esc_rows: the same expand / sort / sum by 8 lanes, so a 64-lane
 //                            workgroup has the gather chains of eight rows in flight
-//   P_i <= ESC_S_CAP (512)   k_esc: one 64-lane workgroup expands the products into LDS, bitonic
-//                            sort by column, runs of equal columns summed
+//   P_i <= ESC_S_CAP (512)   k_esc: one 64-lane workgroup expands the products into LDS, sorts them by
+//                            column, sums the runs of equal columns
+//                            (both sort (column, product number) words in registers, a bitonic network of
+//                            min/max pairs and DPP moves, while the column ids leave room for the product
+//                            number; wider matrices sort in LDS)
 //   P_i <= 4096 (SPMM_ESC_MAX, at most ESC_R_CAP = 8192)
 //                            k_escr: expand (column, index) pairs, stable LSD radix sort in LDS,
-//                            runs summed in product order; independent of the column span
+//                            runs summed in product order; independent of the column span.  Its rows of
+//                            up to ESC_W_CAP (1024) products and more than four entries go to k_esc as
+//                            well (sixteen keys per lane) when the column ids have at most 22 bits
 //   larger                   "window" rows, one workgroup per row, heaviest first, over the
 //                            window-pointer table of B (k_winptr): T[k][w] = first position of B
 //                            row k with column >= w << shift, so the part of a B row inside a
