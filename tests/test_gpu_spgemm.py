@@ -51,6 +51,9 @@ PLANS = {
     "sorted_rows_up_to_4096": {"SPMM_ESC_MAX": "4096"},
     "sorted_rows_up_to_512": {"SPMM_ESC_MAX": "512"},
     "small_cursor_workgroups": {"SPMM_LIGHT_MAX": "65535"},
+    # the rule of 256 products per table window without its floor of 8192: on the narrow test matrices the 1024-thread
+    # cursor workgroups then take the rows from 257 products, as they do from 65 537 on a matrix of 2^22 columns
+    "cursor_rows_from_257_products": {"SPMM_LIGHT_MAX": "256"},
     "small_cursor_workgroups_one_level": {"SPMM_LIGHT_MAX": "65535", "SPMM_LIGHT_TWO": "0", "SPMM_LIGHT_SYM": "0"},
     "rows_not_shared": {"SPMM_SPLIT_GIANT": "0"},
     "split_rows_two_workgroups": {"SPMM_DENSE_MIN": "1", "SPMM_GIANT_LEN": "8", "SPMM_GIANT_MAJOR": "0", "SPMM_GIANT_TASKS": "2",
