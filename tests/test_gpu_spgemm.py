@@ -260,6 +260,41 @@ def test_product_very_wide_b(ctx, log_ncol):
     assert np.array_equal(ci, oi) and np.array_equal(cd, od)
 
 
+@pytest.mark.parametrize("ncol", [1 << 22, (1 << 22) + 1, 1 << 23, (1 << 23) + 1, 1 << 26, (1 << 26) + 1])
+def test_sorted_rows_at_the_limits_of_the_register_sort(ctx, ncol):
+    """The sorting kernels keep (column << bits | product number) words in registers while the column ids leave room
+    for the product number: 26 bits for rows of up to 64 products, 23 up to 512, 22 up to 1024.  Rows with exactly 63,
+    64, 65, 128, 129, 256, 257, 384, 512, 513, 1024 and 1025 products, few and many entries, over matrices one column
+    below and above each limit, with B's columns at the top of the range (the largest words there are) and repeated
+    across its rows (runs of equal columns to sum)."""
+    rng = np.random.default_rng(31)
+    lens = [300] * 4 + [128] * 28 + [16] * 16 + [1] * 16            # rows of B
+    pool = np.arange(ncol - 700, ncol, dtype=np.int64)
+    b_ip = np.zeros(len(lens) + 1, np.int32)
+    b_ip[1:] = np.cumsum(lens)
+    b_ix = np.concatenate([np.sort(rng.choice(pool, n, replace=False)) for n in lens]).astype(np.int32)
+    assert (b_ix[b_ip[1:] - 1] == ncol - 1).any()                     # the last column is some rows' last product
+    b_d = rng.integers(1, 4, b_ix.size).astype(np.float64)
+    big, mid, small, one = list(range(0, 4)), list(range(4, 32)), list(range(32, 48)), list(range(48, 64))
+    rows = [mid[:8], mid[1:8] + small[:8], mid[:8] + one[:1], mid[:4], mid[:4] + one[:1], mid[:3] + small[:8] + one[:1],
+            mid[:3], mid[:2], mid[:2] + one[:1], mid[:1], mid[:1] + one[:1], small[:4], small[:4] + one[:1],
+            small[:3] + one[:15], big[:2], big[:3] + mid[4:5], big[:3] + small[:7] + one[:12], [mid[0]] * 1 + small[:16] + one[:16],
+            mid[20:28], one[:5], []]
+    a_ip = np.zeros(len(rows) + 1, np.int32)
+    a_ip[1:] = np.cumsum([len(r) for r in rows])
+    a_ix = np.concatenate([np.sort(np.array(r, np.int32)) for r in rows if r]).astype(np.int32)
+    a_d = rng.integers(1, 4, a_ix.size).astype(np.float64)
+    prod, _ = orc.row_products(a_ip, a_ix, b_ip)
+    assert {63, 64, 65, 128, 129, 256, 257, 384, 512, 513, 1024, 1025} <= set(int(x) for x in prod)
+    A, B = capi.Csr(len(rows), len(lens), a_ip, a_ix, a_d), capi.Csr(len(lens), ncol, b_ip, b_ix, b_d)
+    c_ip, _, _ = ctx.spgemm_symbolic(A, B)
+    o_ip = orc.spgemm_symbolic(len(rows), ncol, a_ip, a_ix, b_ip, b_ix)
+    assert np.array_equal(c_ip, o_ip)
+    ci, cd = ctx.spgemm_numeric(A, B, c_ip)
+    oi, od, _ = orc.spgemm_numeric(ncol, (a_ip, a_ix, a_d), (b_ip, b_ix, b_d), o_ip)
+    assert np.array_equal(ci, oi) and np.array_equal(cd, od)
+
+
 def test_product_heavy_rows_all_bins(ctx):
     """A matrix whose rows fall in every bin, including rows with more distinct output columns
     than one value sweep holds and duplicate entries in A (kept by the reference loader)."""
