@@ -140,6 +140,48 @@ def test_block_with_more_elements_than_the_lds_renumbering_holds(ctx):
     _compare(ctx.trace_formats(capi.Csr(n, n, ip, ix, d)), o)
 
 
+def test_blocks_of_random_matrices_and_thresholds(ctx):
+    """gen_blocks against the oracle on 24 random matrices (empty rows, repeated columns inside a row, a few long rows)
+    with thresholds from 1 (every row that has an entry ends a block) to more columns than the matrix has."""
+    rng = np.random.default_rng(3)
+    for trial in range(24):
+        n = int(rng.integers(5, 600))
+        m = int(rng.integers(1, 20000))
+        row = rng.integers(0, n, m)
+        col = rng.integers(0, max(2, n // int(rng.integers(1, 8))), m)
+        if trial % 3 == 0:                      # a few rows hold most entries
+            row[: m // 2] = rng.integers(0, 3, m // 2)
+        keep = row % int(rng.integers(2, 7)) != 0
+        row, col = row[keep], col[keep]
+        if row.size == 0:
+            continue
+        ip, ix, d = orc.csr_from_coo(n, row, col)
+        R = capi.Csr(n, n, ip, ix, d)
+        for thr in (1, 3, 17, 64, 300, 100000):
+            want = orc.gen_blocks(n, ip, ix, thr)
+            got = ctx.gen_blocks(R, thr, cap=n + 8)
+            assert np.array_equal(got, want), (trial, n, thr, got[:8], want[:8])
+
+
+def test_pipeline_of_random_matrices(ctx):
+    """Every array of the pipeline against the oracle on random matrices with random section widths and thresholds
+    (panels of one row, blocks of one row, rows longer than 32, empty rows)."""
+    rng = np.random.default_rng(8)
+    for trial in range(12):
+        n = int(rng.integers(9, 3000))
+        m = int(rng.integers(1, 40000))
+        row = rng.integers(0, n, m)
+        col = rng.integers(0, n, m)
+        if trial % 2 == 0:
+            row[: m // 3] = rng.integers(0, 5, m // 3)
+        ip, ix, d = orc.csr_from_coo(n, row, col)
+        d = rng.integers(1, 9, d.size).astype(np.float64)
+        sect, thr = int(rng.choice([1, 7, 64, 2048])), int(rng.choice([1, 5, 40, 700, 65536]))
+        o = orc.trace_formats(n, ip, ix, d, sect=sect, threshold=thr, sort_mode=1)
+        g = ctx.trace_formats(capi.Csr(n, n, ip, ix, d), sect=sect, threshold=thr)
+        _compare(g, o)
+
+
 def test_pipeline_block_capacity_is_an_error(ctx):
     n = 1 << 11
     row, col = synth.rmat(11, 8, 21, True)
