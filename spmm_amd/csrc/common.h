@@ -152,7 +152,8 @@ struct spmm_ctx {
     long long dense_min = -1;   // rows with at least this many intermediate products use k_dense; 0 = off, < 0 = by the number of table windows
     int chain_sweep = 1;           // the greedy block chain as a two-pointer sweep over all row starts and a walk
                                    // (0: one launch per step of the chain)
-    int renumber_lds = 1;          // first-touch renumbering block by block in LDS (0: over the whole stream at once)
+    int renumber_lds = 1;          // first-touch renumbering block by block in LDS (0: over the whole stream at once;
+                                   // 2: always from two sorts, by column and by block, as when one 32-bit key cannot hold both)
     int sweep_chunks = -1;         // waves of the sweep (each counts one block's window first); -1: by the input's size
     int slab_mode = -1;     // window rows over B's slab order instead of the window table: 1 always, 0 never, < 0 when the table exceeds table_max_bytes
     long long table_max_bytes = 96ll << 30;

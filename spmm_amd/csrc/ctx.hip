@@ -74,7 +74,7 @@ int read_switches(spmm_ctx* c) {
     ok = ok && env_int("SPMM_DENSE_KEEP_MIB", 0, 1ll << 26, &c->dense_keep_mib);
     ok = ok && env_int("SPMM_MAX_GRID_THREADS", 1024, (1ll << 32) - 1, &c->max_grid_threads);
     ok = ok && env_int("SPMM_CHAIN_SWEEP", 0, 1, &c->chain_sweep);
-    ok = ok && env_int("SPMM_RENUMBER_LDS", 0, 1, &c->renumber_lds);
+    ok = ok && env_int("SPMM_RENUMBER_LDS", 0, 2, &c->renumber_lds);
     ok = ok && env_int("SPMM_SWEEP_CHUNKS", -1, 1 << 20, &c->sweep_chunks);
     ok = ok && env_int("SPMM_SLAB", -1, 1, &c->slab_mode);
     ok = ok && env_int("SPMM_TABLE_MAX_MIB", 0, 1ll << 30, &c->table_max_mib);  // window table of B beyond this: slab order

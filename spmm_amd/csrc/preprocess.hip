@@ -1004,6 +1004,28 @@ __global__ void __launch_bounds__(256) k_block_head_counts(int64_t n, const uint
     if (lane == 0 && acc > 0) atomicAdd(&counts[cur], acc);
 }
 
+// Block and column numbers wider than 32 bits together: the stream sorted by (column, position) is sorted again, stably,
+// by the block of each position (k_block_of_pos gives the keys), the column ids are fetched back through the positions,
+// and the counts are taken per block.
+__global__ void k_block_of_pos(int64_t n, const uint32_t* __restrict__ pos, const int32_t* __restrict__ bnnz, int32_t bnum,
+                               uint32_t* __restrict__ blk) {
+    GRID_STRIDE(i, n) blk[i] = (uint32_t)last_le(bnnz, bnum + 1, (int)pos[i]);
+}
+__global__ void k_cols_of_pos(int64_t n, const uint32_t* __restrict__ pos, const int32_t* __restrict__ stream, uint32_t* __restrict__ col) {
+    GRID_STRIDE(i, n) col[i] = (uint32_t)stream[pos[i]];
+}
+__global__ void __launch_bounds__(256) k_block_head_counts_by_block(const uint32_t* __restrict__ cs, const int32_t* __restrict__ bnnz,
+                                                                    int32_t* __restrict__ counts) {
+    __shared__ int32_t tmp[4];
+    const int b = blockIdx.x, e0 = bnnz[b], e1 = bnnz[b + 1];
+    int c = 0;
+    for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) c += (i == e0 || cs[i - 1] != cs[i]) ? 1 : 0;
+    c = wave_reduce_sum(c);
+    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+}
+
 __global__ void __launch_bounds__(RN_THREADS) k_renumber_block(const uint32_t* __restrict__ cs, const uint32_t* __restrict__ psd,
                                                                const int32_t* __restrict__ bnnz, const int32_t* __restrict__ seq_offset,
                                                                uint32_t col_mask, int32_t* __restrict__ local,
@@ -1331,25 +1353,37 @@ int dev_first_touch(spmm_ctx* ctx, int32_t ncol, int32_t nnz, int32_t bnum, cons
     CHK(ws(ctx, WS_MISC3, (size_t)bnum + 2, &bnnz));
     hipLaunchKernelGGL(k_block_nnz_starts, dim3(grid_for(bnum + 1, 256)), dim3(256), 0, ctx->stream, bnum, bsize, r_ip, bnnz);
     const int col_bits = bits_for(ncol > 0 ? (uint32_t)(ncol - 1) : 0u), blk_bits = bits_for(bnum > 1 ? (uint32_t)(bnum - 1) : 0u);
-    if (ctx->renumber_lds && nnz > 0 && bnum > 0 && col_bits + blk_bits <= 32) {
+    if (ctx->renumber_lds && nnz > 0 && bnum > 0) {
         // block by block in LDS, from the stream sorted by (block, column, position)
         uint32_t *k0, *v0;
         int32_t *counts, *unfit;
-        CHK(ws(ctx, WS_RADIX_K0, (size_t)nnz + 1, &k0));
-        CHK(ws(ctx, WS_RADIX_V0, (size_t)nnz + 1, &v0));
-        CHK(ws(ctx, WS_RADIX_K1, (size_t)nnz + 1, &cs));
-        CHK(ws(ctx, WS_RADIX_V1, (size_t)nnz + 1, &psd));
+        const bool one_key = ctx->renumber_lds == 1 && col_bits + blk_bits <= 32;
         CHK(ws(ctx, WS_MISC1, (size_t)bnum + 2, &counts));
         CHK(ws(ctx, WS_COUNTERS, 64, &unfit));
         HIPCHK(hipMemsetAsync(unfit, 0, sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(k_block_col_keys, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, stream, bnnz, bnum, col_bits, k0);
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)nnz);
-        CHK(dev_radix_sort_pairs(ctx, k0, v0, cs, psd, nnz, col_bits + blk_bits));
-        HIPCHK(hipMemsetAsync(counts, 0, sizeof(int32_t) * ((size_t)bnum + 1), ctx->stream));
-        hipLaunchKernelGGL(k_block_head_counts, dim3((unsigned)(((int64_t)nnz + 256 * HC_STEPS - 1) / (256 * HC_STEPS))), dim3(256), 0, ctx->stream,
-                           (int64_t)nnz, cs, col_bits, counts);
+        if (one_key) {      // block number above the column id in one 32-bit key
+            CHK(ws(ctx, WS_RADIX_K0, (size_t)nnz + 1, &k0));
+            CHK(ws(ctx, WS_RADIX_V0, (size_t)nnz + 1, &v0));
+            CHK(ws(ctx, WS_RADIX_K1, (size_t)nnz + 1, &cs));
+            CHK(ws(ctx, WS_RADIX_V1, (size_t)nnz + 1, &psd));
+            hipLaunchKernelGGL(k_block_col_keys, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, stream, bnnz, bnum, col_bits, k0);
+            hipLaunchKernelGGL(k_iota, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, v0, (int64_t)nnz);
+            CHK(dev_radix_sort_pairs(ctx, k0, v0, cs, psd, nnz, col_bits + blk_bits));
+            HIPCHK(hipMemsetAsync(counts, 0, sizeof(int32_t) * ((size_t)bnum + 1), ctx->stream));
+            hipLaunchKernelGGL(k_block_head_counts, dim3((unsigned)(((int64_t)nnz + 256 * HC_STEPS - 1) / (256 * HC_STEPS))), dim3(256), 0, ctx->stream,
+                               (int64_t)nnz, cs, col_bits, counts);
+        } else {            // two stable sorts: by column, then by the block of the position
+            CHK(sort_stream_by_col(ctx, stream, nnz, ncol, &cs, &psd));
+            CHK(ws(ctx, WS_RADIX_K0, (size_t)nnz + 1, &k0));
+            CHK(ws(ctx, WS_RADIX_V0, (size_t)nnz + 1, &v0));
+            hipLaunchKernelGGL(k_block_of_pos, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, psd, bnnz, bnum, k0);
+            HIPCHK(hipMemcpyAsync(v0, psd, sizeof(uint32_t) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream));
+            CHK(dev_radix_sort_pairs(ctx, k0, v0, cs, psd, nnz, blk_bits));
+            hipLaunchKernelGGL(k_cols_of_pos, dim3(grid_for(nnz, 256)), dim3(256), 0, ctx->stream, (int64_t)nnz, psd, stream, cs);
+            hipLaunchKernelGGL(k_block_head_counts_by_block, dim3(bnum), dim3(256), 0, ctx->stream, cs, bnnz, counts);
+        }
         CHK(dev_exclusive_scan_i32(ctx, counts, seq_offset, bnum));     // seq_offset[bnum] = number of keys
-        const uint32_t col_mask = col_bits >= 32 ? 0xffffffffu : (1u << col_bits) - 1u;
+        const uint32_t col_mask = !one_key || col_bits >= 32 ? 0xffffffffu : (1u << col_bits) - 1u;
         hipLaunchKernelGGL(k_renumber_block, dim3(bnum), dim3(RN_THREADS), 0, ctx->stream, cs, psd, bnnz, seq_offset, col_mask, local, keys,
                            unfit);
         HIPCHK(hipMemcpyAsync(h, seq_offset + bnum, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

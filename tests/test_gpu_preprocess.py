@@ -20,7 +20,10 @@ STAGES = ["seq_bitmap", "r_indptr", "r_indices", "r_data", "bsize_list", "panel_
 CHAINS = {"sweep": {}, "sweep_one_chunk": {"SPMM_SWEEP_CHUNKS": "1"}, "sweep_chunk_per_row": {"SPMM_SWEEP_CHUNKS": "1048576"},
           "stepwise": {"SPMM_CHAIN_SWEEP": "0"},
           # the first-touch renumbering over the whole stream at once instead of block by block in LDS
-          "renumber_whole_stream": {"SPMM_RENUMBER_LDS": "0"}}
+          "renumber_whole_stream": {"SPMM_RENUMBER_LDS": "0"},
+          # block by block in LDS, but from two stable sorts (by column, then by block) instead of one sort of a 32-bit
+          # (block, column) key: the form for block and column numbers of more than 32 bits together
+          "renumber_two_sorts": {"SPMM_RENUMBER_LDS": "2"}}
 
 
 @pytest.fixture(scope="module", params=list(CHAINS))

@@ -43,7 +43,11 @@ def main():
                    blocks=int(g["bnum"]), gpu_csr_build_kernel_ms=round(csr_ms, 3), gpu_trace_formats_kernel_ms=round(gpu_ms, 3),
                    gpu_trace_formats_wall_ms_with_pcie=round(wall_ms, 1), cpu_oracle_ms=round(cpu_ms, 1),
                    gpu_equals_oracle=bool(same), gpu_stage_ms=stages)
-        if ref.available():
+        if ref.available() and scale > 22:
+            # the compiled reference does not survive this size (std::bad_array_new_length or a corrupted heap in its
+            # own allocations, which takes the process down): it is not run
+            out["cpu_reference_ms"] = None
+        elif ref.available():
             ref.set_csr(n, ip, ix, d)
             t0 = time.perf_counter()
             ref.trace_formats(n, int(ix.size))
