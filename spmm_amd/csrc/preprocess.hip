@@ -1198,10 +1198,13 @@ int dev_gen_blocks(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const
         HIPCHK(hipMemsetAsync(rs_bits, 0, nwords * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_row_start_bits, dim3(grid_for((int64_t)nrow + 1, 256)), dim3(256), 0, ctx->stream, nrow, nnz, r_ip, rs_bits);
         // a chunk counts one whole window (at least `threshold` elements) before it moves row by row, and its rows are
-        // a serial chain: 8192 waves (a full chip) unless the input is too small to give each a few rows
+        // a serial chain: 8192 waves (a full chip; more for inputs beyond scale 23) unless the input is too small to give each
+        // a few rows
         const long long weight = (long long)nnz + (long long)SW_ROW_WEIGHT * nrow;
         long long nchunk = weight / 4096 + 1;
-        if (nchunk > 8192) nchunk = 8192;
+        long long most = weight / 32768;                           // beyond a full chip only for rows' sake: 16 384 chunks at
+        most = most < 8192 ? 8192 : most > 32768 ? 32768 : most;   // scale 24 took 1.4 ms off the stage's 25.6, 32 768 no more
+        if (nchunk > most) nchunk = most;
         if (ctx->sweep_chunks > 0) nchunk = ctx->sweep_chunks;      // as asked for; chunks without rows do nothing
         if (nnz > 0)
             hipLaunchKernelGGL(k_block_sweep, dim3((unsigned)((nchunk + 3) / 4)), dim3(256), 0, ctx->stream, nrow, nnz, r_ip, pn, rs_bits,
