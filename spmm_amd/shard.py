@@ -63,13 +63,14 @@ def product_balanced_bounds(prod, world):
 
 # Cost model of a row shard, in ns per intermediate product and ns per row by the kernel class of the row, fitted
 # to the times (symbolic + numeric, one MI355X, R-MAT scale 22) of the rows of every range of products taken as a
-# matrix of their own (tools/class_cost.py).  The sorted rows are dear per product, the cursor rows per row.  A
+# matrix of their own (tools/class_cost.py; the sorted rows, whose keys are sorted in registers, from that and from a
+# web-Google-sized graph: 13 ps per product and 0.2 ns per row).  The sorted rows are dear per product, the cursor rows per row.  A
 # dense row pays per entry of its row of A as well (the bounds of every table window, gathered into the row's bound
 # table and read again per window): 3.0 ns per entry next to 3.6 ps per product when the row lengths are given, a
 # tenth more for the rows of more than 8192 entries that several workgroups share; 5.7 ps per product stands for
 # both when they are not.  Only the ratios matter.
-COST_NS = {"dense": 0.0057, "window": 0.0070, "light": 0.0078, "sorted": 0.0239}
-ROW_NS = {"dense": 0.0, "window": 120.0, "light": 47.0, "sorted": 6.6}
+COST_NS = {"dense": 0.0057, "window": 0.0070, "light": 0.0078, "sorted": 0.0131}
+ROW_NS = {"dense": 0.0, "window": 120.0, "light": 47.0, "sorted": 0.2}
 DENSE_WITH_LENS_NS = 0.0036
 DENSE_ENTRY_NS = 3.0
 DENSE_ENTRY_WINDOW_POWER = 0.55   # measured: 8 shards at scale 24 (1024 windows) balance at 2.1 times the cost per entry of 256 windows
