@@ -200,7 +200,8 @@ int spmm_csr_from_coo_opts_dev(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_
  *      sect is the reference's SECT (2048, :19), threshold its 65536 (transmat.h:339).
  *      Requires ncol <= nrow (wbsort.h:88 indexes rows by column id).  Panel ties are ordered
  *      by (length, row id): the reference's std::sort order is unspecified.
- *      Returns SPMM_E_CAPACITY when more than cap_blocks blocks are needed. */
+ *      Returns SPMM_E_CAPACITY when more than cap_blocks blocks are needed, SPMM_E_ARG for more than
+ *      2^31 - 65537 entries (the stage calls below likewise: the kernels index the stream with 32 bits). */
 typedef struct {
     int32_t* seq_bitmap; int32_t* r_indptr; int32_t* r_indices; double* r_data;
     int32_t* bsize_list; int32_t* seq_offset; int32_t cap_blocks;

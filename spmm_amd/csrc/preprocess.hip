@@ -25,6 +25,10 @@ inline unsigned grid_for(int64_t n, int threads, int cap = 256 * 16) {
     return (unsigned)g;
 }
 
+// The kernels index the stream with 32-bit integers and look a tile ahead (position + 8192 at most): entries up to this
+// many keep that arithmetic inside the type, more are refused.
+constexpr int32_t PRE_NNZ_MAX = INT32_MAX - (1 << 16);
+
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
@@ -1485,7 +1489,7 @@ int d2h(spmm_ctx* ctx, T* host, const T* dev, size_t count) {
 
 extern "C" int spmm_trace_formats(spmm_ctx* ctx, const spmm_csr* A, int32_t sect, int32_t threshold, spmm_trace* o) {
     ARGCHK(ctx != nullptr && A != nullptr && o != nullptr);
-    ARGCHK(A->nrow >= 0 && A->ncol >= 0 && A->nnz >= 0 && A->indptr != nullptr);
+    ARGCHK(A->nrow >= 0 && A->ncol >= 0 && A->nnz >= 0 && A->nnz <= PRE_NNZ_MAX && A->indptr != nullptr);
     ARGCHK(A->nnz == 0 || (A->indices != nullptr && A->data != nullptr));
     ARGCHK(sect > 0 && threshold > 0 && o->cap_blocks >= 1);
     ARGCHK(A->ncol <= A->nrow);   // the write-back sequence indexes rows by column id (wbsort.h:88)
@@ -1589,7 +1593,7 @@ int h2d_new(spmm_ctx* ctx, PoolGuard& g, const T* host, size_t count, T** dev) {
     return SPMM_OK;
 }
 int check_host_csr(const spmm_csr* M) {
-    ARGCHK(M != nullptr && M->nrow >= 0 && M->ncol >= 0 && M->nnz >= 0 && M->indptr != nullptr);
+    ARGCHK(M != nullptr && M->nrow >= 0 && M->ncol >= 0 && M->nnz >= 0 && M->nnz <= PRE_NNZ_MAX && M->indptr != nullptr);
     ARGCHK(M->nnz == 0 || (M->indices != nullptr && M->data != nullptr));
     return SPMM_OK;
 }
@@ -1718,7 +1722,7 @@ extern "C" int spmm_panels_sort_pack(spmm_ctx* ctx, const spmm_csr* R, const int
 extern "C" int spmm_first_touch(spmm_ctx* ctx, int32_t nrow, int32_t ncol, int32_t nnz, const int32_t* r_indptr,
                                 const int32_t* bsize_list, int32_t bnum, const int32_t* b_colidx_orig, int32_t* b_local,
                                 int32_t* keys, int32_t* n_keys, int32_t* seq_offset) {
-    ARGCHK(ctx != nullptr && nrow >= 0 && ncol >= 0 && nnz >= 0 && bnum >= 1);
+    ARGCHK(ctx != nullptr && nrow >= 0 && ncol >= 0 && nnz >= 0 && nnz <= PRE_NNZ_MAX && bnum >= 1);
     ARGCHK(r_indptr != nullptr && bsize_list != nullptr && n_keys != nullptr && (nnz == 0 || b_colidx_orig != nullptr));
     HIPCHK(hipSetDevice(ctx->device));
     const size_t n = (size_t)nrow, z = (size_t)nnz;

@@ -185,6 +185,20 @@ def test_pipeline_of_random_matrices(ctx):
         _compare(g, o)
 
 
+def test_entry_count_without_room_for_index_arithmetic_is_refused(ctx):
+    """The kernels index the stream with 32-bit integers and look up to a tile ahead of a position; an entry count
+    within 65 536 of the largest int32 is refused (SPMM_E_ARG) before any array is touched."""
+    import ctypes as C
+    ip = np.zeros(9, np.int32)
+    one = np.zeros(1, np.int32)
+    val = np.zeros(1, np.float64)
+    for nnz, code in ((2 ** 31 - 1, -1), (2 ** 31 - 65535, -1)):
+        v = capi.CsrView(8, 8, nnz, ip.ctypes.data, one.ctypes.data, val.ctypes.data)
+        keys = np.zeros(8, np.int32)
+        rc = capi.lib().spmm_row_keys(ctx._h, C.byref(v), C.c_int32(2048), keys.ctypes.data_as(C.c_void_p))
+        assert rc == code, (nnz, rc)
+
+
 def test_pipeline_block_capacity_is_an_error(ctx):
     n = 1 << 11
     row, col = synth.rmat(11, 8, 21, True)
